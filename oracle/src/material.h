@@ -1,0 +1,238 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md). Not part of the product path.
+//
+// Texture (texture.rs:7-70), Material (material.rs:7-133) and the cosine PDF pieces of
+// pdf.rs:13-39, restated in C++17 / f64.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "alias.h"
+
+namespace orc {
+
+// ---- texture.rs ------------------------------------------------------------------------
+struct Texture {
+  enum Kind { Solid, Checker, Image, Normal, UV } kind = Solid;
+  V3 color;                                   // Solid
+  std::shared_ptr<const Texture> odd, even;   // Checker
+  std::shared_ptr<const std::vector<uint8_t>> texels;  // Image: RGB8 row-major
+  uint32_t width = 0, height = 0;
+
+  static Texture solid(V3 c) {
+    Texture t;
+    t.kind = Solid;
+    t.color = c;
+    return t;
+  }
+  static Texture checker(Texture odd, Texture even) {  // texture.rs:17-19
+    Texture t;
+    t.kind = Checker;
+    t.odd = std::make_shared<const Texture>(std::move(odd));
+    t.even = std::make_shared<const Texture>(std::move(even));
+    return t;
+  }
+  static Texture checker_color(V3 odd, V3 even) {  // texture.rs:21-23
+    return checker(solid(odd), solid(even));
+  }
+  // texture.rs:25-31 minus the decode (image crate not available: texels are handed in
+  // already decoded to RGB8; "parity unpinned" against jpeg-decoder 0.1.22).
+  static Texture image(std::shared_ptr<const std::vector<uint8_t>> px, uint32_t w, uint32_t h) {
+    Texture t;
+    t.kind = Image;
+    t.texels = std::move(px);
+    t.width = w;
+    t.height = h;
+    return t;
+  }
+  static Texture normal() {
+    Texture t;
+    t.kind = Normal;
+    return t;
+  }
+  static Texture uv() {
+    Texture t;
+    t.kind = UV;
+    return t;
+  }
+
+  // texture.rs:33-69
+  V3 value(V2 uv, V3 p, V3 normal) const {
+    switch (kind) {
+      case Solid:
+        return color;
+      case Checker: {
+        double scale = 10.0;
+        double sines = std::sin(scale * p.x) * std::sin(scale * p.y) * std::sin(scale * p.z);
+        if (sines < 0.0) return odd->value(uv, p, normal);
+        return even->value(uv, p, normal);
+      }
+      case Image: {
+        double u = std::fmin(std::fmax(uv.x, 0.0), 1.0);
+        double v = std::fmin(std::fmax(uv.y, 0.0), 1.0);
+        v = 1.0 - v;
+        // Rust `as u32` saturates and maps NaN to 0.
+        auto to_u32 = [](double f) -> uint32_t {
+          if (!(f == f)) return 0u;
+          if (f <= 0.0) return 0u;
+          if (f >= 4294967295.0) return 4294967295u;
+          return (uint32_t)f;
+        };
+        uint32_t x = to_u32(u * (double)width);
+        uint32_t y = to_u32(v * (double)height);
+        if (x > width - 1) x = width - 1;
+        if (y > height - 1) y = height - 1;
+        double color_scale = 1.0 / 255.0;
+        const uint8_t* px = texels->data() + 3 * ((size_t)y * width + x);
+        return {px[0] * color_scale, px[1] * color_scale, px[2] * color_scale};
+      }
+      case Normal:
+        return {std::fabs(normal.x), std::fabs(normal.y), std::fabs(normal.z)};
+      case UV:
+        return {uv.x, uv.y, 0.0};
+    }
+    return {};
+  }
+};
+
+// ---- material.rs -----------------------------------------------------------------------
+struct Material;
+
+struct HitRecord {  // hittable.rs:8-40
+  V3 p, normal;
+  double t = 0;
+  V2 uv;
+  bool front_face = false;
+  const Material* material = nullptr;
+  uint32_t object_id = 0xFFFFFFFFu;  // oracle bookkeeping: index of the world-level object
+
+  static HitRecord make(const Ray& r, V3 p, double t, V2 uv, V3 outward_normal,
+                        const Material* m) {
+    HitRecord h;
+    h.front_face = dot(r.direction, outward_normal) < 0.0;
+    h.p = p;
+    h.t = t;
+    h.uv = uv;
+    h.normal = h.front_face ? outward_normal : -outward_normal;
+    h.material = m;
+    return h;
+  }
+};
+
+struct ScatterRecord {
+  enum Kind { None, Specular, Pdf } kind = None;
+  Ray ray;          // Specular
+  V3 attenuation;   // both
+  ONB cosine;       // Pdf: PDF::Cosine(ONB)
+};
+
+// material.rs:128-133
+inline double reflectance(double cosine, double ref_idx) {
+  double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+  r0 = r0 * r0;
+  double m = 1.0 - cosine;
+  double m2 = m * m;  // powi(5) by repeated squaring, as llvm.powi expands it
+  double m4 = m2 * m2;
+  return r0 + (1.0 - r0) * (m4 * m);
+}
+
+struct Material {
+  enum Kind { Lambertian, Dielectric, Metal, DiffuseLight, Isotropic } kind = Lambertian;
+  Texture texture;  // Lambertian / DiffuseLight / Isotropic
+  double ir = 1.0;  // Dielectric
+  V3 albedo;        // Metal
+  double fuzz = 0;  // Metal
+
+  static Material lambertian(V3 albedo) { return lambertian_tex(Texture::solid(albedo)); }
+  static Material lambertian_tex(Texture t) {
+    Material m;
+    m.kind = Lambertian;
+    m.texture = std::move(t);
+    return m;
+  }
+  static Material dielectric(double ir) {
+    Material m;
+    m.kind = Dielectric;
+    m.ir = ir;
+    return m;
+  }
+  static Material metal(V3 albedo, double fuzz) {
+    Material m;
+    m.kind = Metal;
+    m.albedo = albedo;
+    m.fuzz = fuzz;
+    return m;
+  }
+  static Material diffuse_light(V3 emit) {
+    Material m;
+    m.kind = DiffuseLight;
+    m.texture = Texture::solid(emit);
+    return m;
+  }
+  static Material isotropic(V3 albedo) {
+    Material m;
+    m.kind = Isotropic;
+    m.texture = Texture::solid(albedo);
+    return m;
+  }
+
+  // material.rs:57-102
+  ScatterRecord scatter(const Ray& r, const HitRecord& hit, Rng& rng) const {
+    ScatterRecord s;
+    switch (kind) {
+      case Lambertian:
+      case Isotropic: {  // :59-65 and :97-100 are the same computation
+        s.kind = ScatterRecord::Pdf;
+        s.attenuation = texture.value(hit.uv, hit.p, hit.normal);
+        s.cosine = ONB::from_w(hit.normal);
+        return s;
+      }
+      case Dielectric: {
+        double refraction_ratio = hit.front_face ? 1.0 / ir : ir;
+        V3 unit_direction = normalize(r.direction);
+        double cos_theta = std::fmin(dot(-unit_direction, hit.normal), 1.0);
+        double sin_theta = std::sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        V3 direction;
+        // `||` short-circuits: the draw happens only when refraction is possible.
+        if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rng.next_f64())
+          direction = reflect(unit_direction, hit.normal);
+        else
+          direction = refract(unit_direction, hit.normal, refraction_ratio);
+        s.kind = ScatterRecord::Specular;
+        s.ray = Ray{hit.p, direction, r.time};
+        s.attenuation = V3(1.0, 1.0, 1.0);
+        return s;
+      }
+      case Metal: {
+        V3 reflected = reflect(normalize(r.direction), hit.normal);
+        V3 direction = reflected + fuzz * random_in_unit_sphere(rng);
+        s.kind = ScatterRecord::Specular;
+        s.ray = Ray{hit.p, direction, r.time};
+        s.attenuation = albedo;
+        return s;
+      }
+      case DiffuseLight:
+        s.kind = ScatterRecord::None;
+        return s;
+    }
+    return s;
+  }
+
+  // material.rs:104-116
+  double scattering_pdf(const Ray&, const HitRecord& hit, const Ray& scattered) const {
+    if (kind == Lambertian) {
+      double cosine = dot(hit.normal, normalize(scattered.direction));
+      return cosine <= 0.0 ? 0.0 : cosine / PI;
+    }
+    return 1.0;
+  }
+
+  // material.rs:118-125
+  V3 emit(const HitRecord& hit) const {
+    if (kind == DiffuseLight && hit.front_face) return texture.value(hit.uv, hit.p, hit.normal);
+    return V3();
+  }
+};
+
+}  // namespace orc

@@ -1,0 +1,313 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md). Not part of the product path.
+//
+// Camera (cam.rs:6-72), the six reference scenes (scenes.rs:10-192), the fixed camera /
+// background / lights fold of main.rs:125-150, and the three benchmark scenes that
+// BASELINE.json's configs name but the reference does not contain:
+// Cornell box, BVH stress, final-scene composition — built only from reference primitives.
+#pragma once
+#include "hittable.h"
+
+namespace orc {
+
+// ---- cam.rs ------------------------------------------------------------------------------
+struct Camera {
+  V3 origin, lower_left_corner, horizontal, vertical, u, v, w;
+  double lens_radius = 0, time_open = 0, time_close = 1;
+
+  // cam.rs:26-61
+  static Camera make(V3 lookfrom, V3 lookat, V3 vup, double vfov, double aspect_ratio,
+                     double aperture, double focus_dist, double time_open, double time_close) {
+    double theta = vfov * (PI / 180.0);  // f64::to_radians
+    double h = std::tan(theta / 2.0);
+    double viewport_height = 2.0 * h;
+    double viewport_width = aspect_ratio * viewport_height;
+    Camera c;
+    c.w = normalize(lookfrom - lookat);
+    c.u = normalize(cross(vup, c.w));
+    c.v = cross(c.w, c.u);
+    c.origin = lookfrom;
+    c.horizontal = (focus_dist * viewport_width) * c.u;
+    c.vertical = (focus_dist * viewport_height) * c.v;
+    c.lower_left_corner = c.origin - c.horizontal / 2.0 - c.vertical / 2.0 - focus_dist * c.w;
+    c.lens_radius = aperture / 2.0;
+    c.time_open = time_open;
+    c.time_close = time_close;
+    return c;
+  }
+
+  // cam.rs:63-71 — draw order: disk (2 per rejection iteration), then time
+  Ray get_ray(double s, double t, Rng& rng) const {
+    V3 rd = lens_radius * random_in_unit_disk(rng);
+    V3 offset = u * rd.x + v * rd.y;
+    Ray r;
+    r.origin = origin + offset;
+    r.direction = lower_left_corner + s * horizontal + t * vertical - origin - offset;
+    r.time = rng.range(time_open, time_close);
+    return r;
+  }
+};
+
+// f64::to_radians multiplies by (PI / 180.0) as a single rounded constant.
+inline double to_radians(double deg) { return deg * (PI / 180.0); }
+
+struct CameraSpec {
+  V3 lookfrom, lookat, vup;
+  double vfov, aperture, focus_dist, time_open, time_close;
+};
+
+struct SceneSpec {
+  int scene_id = 3;
+  uint64_t scene_seed = 5;  // echoes StdRng::seed_from_u64(5), scenes.rs:64
+  uint32_t n = 0;           // scene 7: number of random spheres
+  std::shared_ptr<const std::vector<uint8_t>> texels;  // earthmap RGB8 for scenes 2, 4, 8
+  uint32_t tex_w = 0, tex_h = 0;
+};
+
+struct SceneDef {
+  std::vector<Hittable> world, lights;
+  CameraSpec cam;
+  V3 background;
+  RotateBBox rotate_bbox = RotateBBox::Reference;
+};
+
+// Scene-construction draw streams (a keyed Philox stream per purpose).
+constexpr uint32_t SCENE_KEY_HI = 0x5CE4E5EEu;
+inline Rng scene_rng(uint64_t seed, uint32_t stream) {
+  Rng r;
+  r.k0 = (uint32_t)seed;
+  r.k1 = (uint32_t)(seed >> 32) ^ SCENE_KEY_HI;
+  r.a = stream;
+  return r;
+}
+
+// main.rs:134-150 — identical for every reference scene
+inline CameraSpec reference_camera() {
+  return {V3(13.0, 2.0, 3.0), V3(0.0, 0.0, 0.0), V3(0.0, 1.0, 0.0), 20.0, 0.1, 10.0, 0.0, 1.0};
+}
+inline V3 reference_background() { return V3(0.50, 0.70, 1.00); }
+
+// scenes.rs:10-28
+inline void two_spheres(SceneDef& s) {
+  Texture checker = Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9));
+  s.world.push_back(Hittable::new_sphere(V3(0.0, -10.0, 0.0), 10.0, Material::lambertian_tex(checker)));
+  s.world.push_back(Hittable::new_sphere(V3(0.0, 10.0, 0.0), 10.0, Material::lambertian_tex(checker)));
+}
+
+// scenes.rs:30-53
+inline void small_scene(SceneDef& s) {
+  Material ground = Material::lambertian(V3(0.8, 0.8, 0.0));
+  Material center = Material::lambertian(V3(0.1, 0.2, 0.5));
+  Material left = Material::dielectric(1.5);
+  Material right = Material::metal(V3(0.8, 0.6, 0.2), 1.0);
+  s.world.push_back(Hittable::new_sphere(V3(0.0, -100.5, -1.0), 100.0, ground));
+  s.world.push_back(Hittable::new_sphere(V3(0.0, 0.0, -1.0), 0.5, center));
+  s.world.push_back(Hittable::new_sphere(V3(-1.0, 0.0, -1.0), 0.5, left));
+  s.world.push_back(Hittable::new_sphere(V3(-1.0, 0.0, -1.0), -0.4, left));
+  s.world.push_back(Hittable::new_sphere(V3(1.0, 0.0, -1.0), 0.5, right));
+}
+
+// scenes.rs:55-123.  The seeded StdRng becomes scene stream 0; the unseeded thread_rng
+// behind Vector::random_vector() (Q18) becomes scene stream 1.
+inline void random_scene(SceneDef& s, uint64_t seed) {
+  Texture checker = Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9));
+  s.world.push_back(Hittable::new_sphere(V3(0.0, -1000.0, 0.0), 1000.0, Material::lambertian_tex(checker)));
+  Rng rng = scene_rng(seed, 0);
+  Rng trng = scene_rng(seed, 1);
+  for (int a = -11; a < 11; ++a) {
+    for (int b = -11; b < 11; ++b) {
+      double choose_mat = rng.next_f64();
+      double cx = (double)a + 0.9 * rng.next_f64();
+      double cz = (double)b + 0.9 * rng.next_f64();
+      V3 center(cx, 0.2, cz);
+      if (length(center - V3(4.0, 0.2, 0.0)) > 0.9) {
+        Material m;
+        if (choose_mat < 0.8) {
+          V3 r1 = random_vector(trng);
+          V3 r2 = random_vector(trng);
+          m = Material::lambertian(r1 * r2);
+        } else if (choose_mat < 0.95) {
+          double ar = rng.range(0.5, 1.0);
+          double ag = rng.range(0.5, 1.0);
+          double ab = rng.range(0.5, 1.0);
+          double fuzz = rng.range(0.0, 0.5);
+          m = Material::metal(V3(ar, ag, ab), fuzz);
+        } else {
+          m = Material::dielectric(1.5);
+        }
+        if (choose_mat < 0.8) {
+          V3 center2 = center + V3(0.0, rng.range(0.0, 0.5), 0.0);
+          s.world.push_back(Hittable::new_moving_sphere(center, center2, 0.0, 1.0, 0.2, m));
+        } else {
+          s.world.push_back(Hittable::new_sphere(center, 0.2, m));
+        }
+      }
+    }
+  }
+  s.world.push_back(Hittable::new_sphere(V3(0.0, 1.0, 0.0), 1.0, Material::dielectric(1.5)));
+  s.world.push_back(Hittable::new_sphere(V3(-4.0, 1.0, 0.0), 1.0, Material::lambertian(V3(0.4, 0.2, 0.1))));
+  s.world.push_back(Hittable::new_sphere(V3(4.0, 1.0, 0.0), 1.0, Material::metal(V3(0.7, 0.6, 0.5), 0.0)));
+}
+
+inline Texture earth_texture(const SceneSpec& spec) {
+  if (!spec.texels || spec.tex_w == 0 || spec.tex_h == 0)
+    throw std::runtime_error("image texture: no texels supplied (scenes.rs:126 unwrap would panic)");
+  return Texture::image(spec.texels, spec.tex_w, spec.tex_h);
+}
+
+// scenes.rs:125-131
+inline void earth(SceneDef& s, const SceneSpec& spec) {
+  s.world.push_back(Hittable::new_sphere(V3(), 2.0, Material::lambertian_tex(earth_texture(spec))));
+}
+
+// scenes.rs:133-175
+inline void simple_light(SceneDef& s) {
+  s.lights.push_back(Hittable::new_sphere(V3(0.0, 2.0, 3.0), 1.0, Material::diffuse_light(V3(4.0, 4.0, 4.0))));
+  s.lights.push_back(Hittable::new_sphere(V3(2.0, 0.3, 1.0), 0.2, Material::dielectric(1.5)));
+  s.world.push_back(Hittable::new_sphere(V3(0.0, -1000.0, 0.0), 1000.0, Material::lambertian(V3(0.8, 0.8, 0.0))));
+  s.world.push_back(Hittable::new_constant_medium(
+      Hittable::new_sphere(V3(0.0, 2.0, 0.0), 2.0, Material::lambertian(V3(0.8, 0.0, 0.0))), 0.91,
+      V3(0.0, 0.0, 0.0)));
+  s.world.push_back(Hittable::new_rotate(
+      Hittable::new_cube(V3(0.0, 1.0, -1.7), V3(4.0, 2.0, -1.6), Material::lambertian_tex(Texture::normal())),
+      to_radians(5.0), V3(0.0, 0.0, 1.0)));
+  for (const auto& l : s.lights) s.world.push_back(l.clone());  // world.append(lights.clone())
+}
+
+// scenes.rs:177-192
+inline void cube_scene(SceneDef& s, const SceneSpec& spec) {
+  s.world.push_back(Hittable::new_rotate(
+      Hittable::new_cube(V3(-1.0, -1.0, -1.0), V3(1.0, 1.0, 1.0), Material::lambertian_tex(earth_texture(spec))),
+      -to_radians(45.0), V3(0.0, 0.0, 1.0)));  // -45.0f64.to_radians() = -(45.0.to_radians())
+}
+
+// ---- scenes without a reference counterpart ------------------------------
+
+// C2 / C5: Cornell box from thin Cubes, a Sphere light (the only light shape the
+// reference can importance-sample, Q8) and two Translate(Rotate(Cube)) boxes.
+inline void cornell_box(SceneDef& s) {
+  Material red = Material::lambertian(V3(0.65, 0.05, 0.05));
+  Material white = Material::lambertian(V3(0.73, 0.73, 0.73));
+  Material green = Material::lambertian(V3(0.12, 0.45, 0.15));
+  Material light = Material::diffuse_light(V3(15.0, 15.0, 15.0));
+  s.world.push_back(Hittable::new_cube(V3(555.0, 0.0, 0.0), V3(556.0, 555.0, 555.0), green));
+  s.world.push_back(Hittable::new_cube(V3(-1.0, 0.0, 0.0), V3(0.0, 555.0, 555.0), red));
+  s.world.push_back(Hittable::new_cube(V3(0.0, -1.0, 0.0), V3(555.0, 0.0, 555.0), white));
+  s.world.push_back(Hittable::new_cube(V3(0.0, 555.0, 0.0), V3(555.0, 556.0, 555.0), white));
+  s.world.push_back(Hittable::new_cube(V3(0.0, 0.0, 555.0), V3(555.0, 555.0, 556.0), white));
+  s.world.push_back(Hittable::new_sphere(V3(278.0, 480.0, 278.0), 60.0, light));
+  // Q4: the object appears turned by −angle, so Shirley's +15° / −18° are passed negated.
+  s.world.push_back(Hittable::new_translate(
+      Hittable::new_rotate(Hittable::new_cube(V3(0.0, 0.0, 0.0), V3(165.0, 330.0, 165.0), white),
+                           to_radians(-15.0), V3(0.0, 1.0, 0.0)),
+      V3(265.0, 0.0, 295.0)));
+  s.world.push_back(Hittable::new_translate(
+      Hittable::new_rotate(Hittable::new_cube(V3(0.0, 0.0, 0.0), V3(165.0, 165.0, 165.0), white),
+                           to_radians(18.0), V3(0.0, 1.0, 0.0)),
+      V3(130.0, 0.0, 65.0)));
+  s.lights.push_back(Hittable::new_sphere(V3(278.0, 480.0, 278.0), 60.0, light));
+  s.cam = {V3(278.0, 278.0, -800.0), V3(278.0, 278.0, 0.0), V3(0.0, 1.0, 0.0), 40.0, 0.0, 10.0, 0.0, 1.0};
+  s.background = V3(0.0, 0.0, 0.0);
+  s.rotate_bbox = RotateBBox::Correct;
+}
+
+// C4: ground + n random static spheres, material mix as random_scene; scene stream 0.
+inline void bvh_stress(SceneDef& s, uint64_t seed, uint32_t n) {
+  Texture checker = Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9));
+  s.world.push_back(Hittable::new_sphere(V3(0.0, -1000.0, 0.0), 1000.0, Material::lambertian_tex(checker)));
+  Rng rng = scene_rng(seed, 0);
+  for (uint32_t i = 0; i < n; ++i) {
+    double choose_mat = rng.next_f64();
+    double cx = rng.range(-40.0, 40.0);
+    double cy = rng.range(0.1, 20.0);
+    double cz = rng.range(-40.0, 40.0);
+    double radius = rng.range(0.05, 0.15);
+    Material m;
+    if (choose_mat < 0.8) {
+      V3 r1 = random_vector(rng);
+      V3 r2 = random_vector(rng);
+      m = Material::lambertian(r1 * r2);
+    } else if (choose_mat < 0.95) {
+      double ar = rng.range(0.5, 1.0);
+      double ag = rng.range(0.5, 1.0);
+      double ab = rng.range(0.5, 1.0);
+      double fuzz = rng.range(0.0, 0.5);
+      m = Material::metal(V3(ar, ag, ab), fuzz);
+    } else {
+      m = Material::dielectric(1.5);
+    }
+    s.world.push_back(Hittable::new_sphere(V3(cx, cy, cz), radius, m));
+  }
+}
+
+// C3: "Next Week" final-scene composition restricted to what the reference can express:
+// a 20×20 floor of Cubes, a Sphere light, a MovingSphere, glass, metal, two
+// ConstantMedium(Sphere) volumes, an earthmap sphere, a checker sphere in place of Perlin
+// noise, and 1000 small white spheres each wrapped Translate(Rotate(Sphere)).
+inline void final_scene(SceneDef& s, const SceneSpec& spec) {
+  Rng rng = scene_rng(spec.scene_seed, 0);
+  Material ground = Material::lambertian(V3(0.48, 0.83, 0.53));
+  const int boxes_per_side = 20;
+  for (int i = 0; i < boxes_per_side; ++i) {
+    for (int j = 0; j < boxes_per_side; ++j) {
+      double w = 100.0;
+      double x0 = -1000.0 + i * w;
+      double z0 = -1000.0 + j * w;
+      double y0 = 0.0;
+      double x1 = x0 + w;
+      double y1 = rng.range(1.0, 101.0);
+      double z1 = z0 + w;
+      s.world.push_back(Hittable::new_cube(V3(x0, y0, z0), V3(x1, y1, z1), ground));
+    }
+  }
+  Material light = Material::diffuse_light(V3(7.0, 7.0, 7.0));
+  s.world.push_back(Hittable::new_sphere(V3(273.0, 654.0, 279.5), 100.0, light));
+  s.lights.push_back(Hittable::new_sphere(V3(273.0, 654.0, 279.5), 100.0, light));
+  V3 center1(400.0, 400.0, 200.0);
+  V3 center2 = center1 + V3(30.0, 0.0, 0.0);
+  s.world.push_back(Hittable::new_moving_sphere(center1, center2, 0.0, 1.0, 50.0, Material::lambertian(V3(0.7, 0.3, 0.1))));
+  s.world.push_back(Hittable::new_sphere(V3(260.0, 150.0, 45.0), 50.0, Material::dielectric(1.5)));
+  s.world.push_back(Hittable::new_sphere(V3(0.0, 150.0, 145.0), 50.0, Material::metal(V3(0.8, 0.8, 0.9), 1.0)));
+  s.world.push_back(Hittable::new_sphere(V3(360.0, 150.0, 145.0), 70.0, Material::dielectric(1.5)));
+  s.world.push_back(Hittable::new_constant_medium(
+      Hittable::new_sphere(V3(360.0, 150.0, 145.0), 70.0, Material::dielectric(1.5)), 0.2, V3(0.2, 0.4, 0.9)));
+  s.world.push_back(Hittable::new_constant_medium(
+      Hittable::new_sphere(V3(0.0, 0.0, 0.0), 5000.0, Material::dielectric(1.5)), 0.0001, V3(1.0, 1.0, 1.0)));
+  s.world.push_back(Hittable::new_sphere(V3(400.0, 200.0, 400.0), 100.0, Material::lambertian_tex(earth_texture(spec))));
+  s.world.push_back(Hittable::new_sphere(
+      V3(220.0, 280.0, 300.0), 80.0,
+      Material::lambertian_tex(Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9)))));
+  Material white = Material::lambertian(V3(0.73, 0.73, 0.73));
+  for (int j = 0; j < 1000; ++j) {
+    double px = rng.range(0.0, 165.0);
+    double py = rng.range(0.0, 165.0);
+    double pz = rng.range(0.0, 165.0);
+    s.world.push_back(Hittable::new_translate(
+        Hittable::new_rotate(Hittable::new_sphere(V3(px, py, pz), 10.0, white), to_radians(-15.0),
+                             V3(0.0, 1.0, 0.0)),
+        V3(-100.0, 270.0, 395.0)));
+  }
+  s.cam = {V3(478.0, 278.0, -600.0), V3(278.0, 278.0, 0.0), V3(0.0, 1.0, 0.0), 40.0, 0.0, 10.0, 0.0, 1.0};
+  s.background = V3(0.0, 0.0, 0.0);
+  s.rotate_bbox = RotateBBox::Correct;
+}
+
+// main.rs:117-124 plus the three extra ids
+inline SceneDef build_scene_def(const SceneSpec& spec) {
+  SceneDef s;
+  s.cam = reference_camera();
+  s.background = reference_background();
+  switch (spec.scene_id) {
+    case 0: random_scene(s, spec.scene_seed); break;
+    case 1: two_spheres(s); break;
+    case 2: earth(s, spec); break;
+    case 3: simple_light(s); break;
+    case 4: cube_scene(s, spec); break;
+    case 6: cornell_box(s); break;
+    case 7: bvh_stress(s, spec.scene_seed, spec.n); break;
+    case 8: final_scene(s, spec); break;
+    default: small_scene(s); break;
+  }
+  return s;
+}
+
+}  // namespace orc
