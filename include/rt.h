@@ -1,0 +1,243 @@
+/*
+ * rt.h — C ABI of librt_hip.so, the MI355X (gfx950) path-tracing hot path.
+ *
+ * The reference (dr-BEat/raytracer) has no FFI seam: the hot path is the rayon closure at
+ * main.rs:154-170 called in-process over `&Camera`, `&Hittable`, `&Option<Hittable>`.  This
+ * header is the seam BASELINE.json's north_star prescribes: the host flattens the
+ * Hittable / Material / Texture / PDF enums (hittable.rs:100-111, material.rs:23-30,
+ * texture.rs:7-14, pdf.rs:5-10) into tagged structure-of-arrays buffers, and calls these
+ * entry points.  Plain pointers and sizes only; every host array is caller-owned and is
+ * copied during the call that receives it; no pointer is retained afterwards.
+ *
+ * All entry points return 0 on success or an rt_status code; rt_last_error() gives the
+ * thread-local message.  Nothing aborts or throws across the boundary (the reference's
+ * panics — scenes.rs:126, main.rs:176, aabb.rs:50, cam.rs:69 — become RT_ERR_BAD_ARG).
+ *
+ * An rt_scene is bound to one device and is not thread-safe; distinct handles may be used
+ * from distinct threads / processes (one process per GPU is how bench.py scales out).
+ */
+#ifndef RT_H
+#define RT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+typedef struct rt_scene rt_scene; /* opaque: one per (scene, device) */
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_BAD_ARG = 1,      /* null pointer, size mismatch, out-of-range index, empty shutter */
+  RT_ERR_HIP = 2,          /* a hip* call failed (no device, OOM, launch failure) */
+  RT_ERR_UNSUPPORTED = 3,  /* scene uses nesting the flat format cannot express */
+  RT_ERR_STACK_DEPTH = 4   /* BVH height exceeds the LDS traversal stack */
+} rt_status;
+
+/* ---- node / leaf references ------------------------------------------------------------
+ * A child reference in node_left / node_right / root is either the pre-order index of
+ * another node, or a leaf:  RT_REF_LEAF | (kind << 28) | index-into-that-kind's-arrays.
+ * RT_REF_NONE as root = Hittable::Empty world (hittable.rs:171, 413).                    */
+#define RT_REF_LEAF 0x80000000u
+#define RT_REF_NONE 0xFFFFFFFFu
+#define RT_REF_KIND(ref) (((ref) >> 28) & 7u)
+#define RT_REF_INDEX(ref) ((ref) & 0x0FFFFFFFu)
+#define RT_MAKE_LEAF(kind, index) (RT_REF_LEAF | ((uint32_t)(kind) << 28) | (uint32_t)(index))
+
+enum rt_leaf_kind {
+  RT_LEAF_SPHERE = 0,   /* Hittable::Sphere        hittable.rs:49-54, 257-287 */
+  RT_LEAF_MSPHERE = 1,  /* Hittable::MovingSphere  hittable.rs:56-72, 288-318 */
+  RT_LEAF_CUBE = 2,     /* Hittable::Cube          hittable.rs:42-47, 210-256 */
+  RT_LEAF_COMPLEX = 3   /* a chain of Translate / Rotate / ConstantMedium wrappers
+                           (hittable.rs:74-91, 319-386) around one of the above */
+};
+
+enum rt_op_tag {        /* one wrapper of a complex object's chain, outermost first */
+  RT_OP_TRANSLATE = 0,  /* data = offset xyz            hittable.rs:364-373 */
+  RT_OP_ROTATE = 1,     /* data = quaternion (w,x,y,z)  hittable.rs:374-386, alias.rs:130-133 */
+  RT_OP_MEDIUM = 2      /* data[0] = neg_inv_density    hittable.rs:319-363; material =
+                           complex_material (Isotropic, hittable.rs:148) */
+};
+
+enum rt_material_tag {  /* material.rs:23-30 */
+  RT_MAT_LAMBERTIAN = 0,
+  RT_MAT_DIELECTRIC = 1,   /* params[0] = ir */
+  RT_MAT_METAL = 2,        /* params[0..2] = albedo, params[3] = fuzz */
+  RT_MAT_DIFFUSE_LIGHT = 3,
+  RT_MAT_ISOTROPIC = 4
+};
+
+enum rt_texture_tag {   /* texture.rs:7-14 */
+  RT_TEX_SOLID = 0,     /* color */
+  RT_TEX_CHECKER = 1,   /* odd / even = texture indices (may nest) */
+  RT_TEX_IMAGE = 2,     /* texel_offset (bytes into texels), width, height; RGB8 row-major */
+  RT_TEX_NORMAL = 3,
+  RT_TEX_UV = 4
+};
+
+enum rt_light_tag {     /* hittable.rs:477-515: only Sphere is importance-sampled */
+  RT_LIGHT_SPHERE = 0,  /* light_sphere = centre xyz, radius */
+  RT_LIGHT_OTHER = 1    /* pdf_value = 0, random = (1,0,0)   (hittable.rs:498, 513) */
+};
+
+enum rt_lights_kind {   /* the fold at main.rs:126-131 */
+  RT_LIGHTS_NONE = 0,   /* None: pure cosine PDF, no mixture draw */
+  RT_LIGHTS_SINGLE = 1, /* Some(x): no List::choose draw */
+  RT_LIGHTS_LIST = 2    /* Some(List): uniform choose, mean pdf */
+};
+
+/* Flat scene, host side.  Geometry is f64 like the reference (alias.rs:4-7); the library
+ * converts to the device precision (f32 for rt_render, f64 for the *_f64 audit entries). */
+typedef struct rt_scene_desc {
+  uint32_t abi_version;           /* RT_ABI_VERSION */
+  uint32_t bvh_height;            /* max number of nodes on a root-to-leaf path (0 if root is a leaf) */
+
+  /* BVH nodes in PRE-ORDER (node, left subtree, right subtree) — hittable.rs:94-98 */
+  uint32_t n_nodes;
+  uint32_t root;
+  const double* node_box;         /* [n_nodes][6] = minimum xyz, maximum xyz (aabb.rs:7-10) */
+  const uint32_t* node_left;      /* [n_nodes] */
+  const uint32_t* node_right;     /* [n_nodes] */
+
+  uint32_t n_spheres;
+  const double* sphere;           /* [n][4] = centre xyz, radius (may be negative, Q15) */
+  const uint32_t* sphere_material;
+  const uint32_t* sphere_object;  /* world-level object id reported by rt_primary_hits */
+
+  uint32_t n_mspheres;
+  const double* msphere;          /* [n][9] = c0 xyz, c1 xyz, radius, time_start, time_end */
+  const uint32_t* msphere_material;
+  const uint32_t* msphere_object;
+
+  uint32_t n_cubes;
+  const double* cube;             /* [n][6] = p0 xyz, p1 xyz */
+  const uint32_t* cube_material;
+  const uint32_t* cube_object;
+
+  uint32_t n_complex;
+  const uint32_t* complex_body;       /* leaf ref of kind SPHERE / MSPHERE / CUBE */
+  const uint32_t* complex_op_first;   /* first wrapper in ops[] */
+  const uint32_t* complex_op_count;   /* number of wrappers, outermost first */
+  const uint32_t* complex_material;   /* Isotropic material of the medium op, else RT_REF_NONE */
+  const uint32_t* complex_object;
+
+  uint32_t n_ops;
+  const uint8_t* op_tag;          /* rt_op_tag */
+  const double* op_data;          /* [n_ops][4] */
+
+  uint32_t n_materials;
+  const uint8_t* mat_tag;         /* rt_material_tag */
+  const uint32_t* mat_texture;    /* texture index, or RT_REF_NONE */
+  const double* mat_params;       /* [n][4] */
+
+  uint32_t n_textures;
+  const uint8_t* tex_tag;         /* rt_texture_tag */
+  const double* tex_color;        /* [n][3] */
+  const uint32_t* tex_odd;
+  const uint32_t* tex_even;
+  const uint64_t* tex_texel_offset;
+  const uint32_t* tex_width;
+  const uint32_t* tex_height;
+
+  uint64_t n_texel_bytes;
+  const uint8_t* texels;          /* RGB8 row-major (image::RgbImage, texture.rs:11) */
+
+  uint32_t lights_kind;           /* rt_lights_kind */
+  uint32_t n_lights;
+  const uint8_t* light_tag;       /* rt_light_tag */
+  const double* light_sphere;     /* [n_lights][4] */
+
+  double background[3];           /* main.rs:139 */
+} rt_scene_desc;
+
+/* = cam.rs:6-18 (w is dead in the reference, cam.rs:13-14) */
+typedef struct rt_camera {
+  double origin[3], lower_left[3], horizontal[3], vertical[3], u[3], v[3];
+  double lens_radius, time_open, time_close;
+} rt_camera;
+
+#define RT_FLAG_STATS 1u  /* count nodes / primitive tests / vertices (slower launch) */
+
+typedef struct rt_params {
+  uint32_t width, height;   /* image size; h = trunc(w / aspect) is the caller's job (main.rs:112) */
+  uint32_t spp;             /* samples per pixel rendered by THIS call */
+  uint32_t max_depth;       /* main.rs:47-48 */
+  uint64_t seed;            /* Philox key */
+  uint64_t sample_offset;   /* global index of this call's first sample (multi-GPU sharding) */
+  uint32_t spp_per_launch;  /* 0 = library default */
+  uint32_t flags;           /* RT_FLAG_* */
+} rt_params;
+
+typedef struct rt_stats {
+  uint64_t rays;            /* ray_color invocations with depth > 0 (main.rs:77) */
+  uint64_t light_probes;    /* Sphere::hit inside pdf_value (hittable.rs:480-482) */
+  uint64_t medium_probes;   /* boundary hits inside ConstantMedium (hittable.rs:324-325) */
+  uint64_t nodes_visited;   /* RT_FLAG_STATS only, as are the next ten */
+  uint64_t sphere_tests, sphere_hits, cube_tests, cube_hits;
+  uint64_t rotate_visits, translate_visits, medium_visits;
+  uint64_t closest_hits, diffuse_vertices, specular_vertices;
+  uint64_t emitter_hits, misses;
+  uint64_t nonfinite_samples; /* samples whose radiance was NaN/inf (f32: dropped) */
+  uint32_t launches;
+  uint32_t reserved;
+  double kernel_ms;         /* HIP-event time over this call's render launches */
+} rt_stats;
+
+/* Replaces: the immutable borrows `&world`, `&lights` captured by the closure at
+ * main.rs:158-169.  Validates every index in the description, copies it to HBM.        */
+int rt_scene_create(int device, const rt_scene_desc* desc, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* Replaces: one `world.hit(r, 0.001, inf)` per pixel (main.rs:77) for the deterministic
+ * primary ray through the pixel centre (no jitter, no lens offset, ray.time = time), with
+ * draw stream (pixel, sample 0, slot 1).  Outputs are host arrays [h][w]...; prim_id is the
+ * world-level object id or RT_REF_NONE; uv / front_face may be null.                     */
+int rt_primary_hits(rt_scene* scene, const rt_camera* cam, uint32_t width, uint32_t height,
+                    uint64_t seed, double time, uint32_t* prim_id, float* t, float* normal /*[.][3]*/,
+                    float* uv /*[.][2]*/, uint8_t* front_face);
+int rt_primary_hits_f64(rt_scene* scene, const rt_camera* cam, uint32_t width, uint32_t height,
+                        uint64_t seed, double time, uint32_t* prim_id, double* t, double* normal,
+                        double* uv, uint8_t* front_face);
+
+/* Replaces: the render closure main.rs:154-167 minus the divide and quantise.  accum_rgb is
+ * a HOST array [h][w][3] that receives the SUM (not the mean) of this call's spp samples.  */
+int rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+              float* accum_rgb, rt_stats* stats);
+/* Audit build of the same kernel in f64 with contraction off: draw-for-draw and
+ * branch-for-branch comparable with the CPU oracle.  Not a production path.             */
+int rt_render_f64(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+                  double* accum_rgb, rt_stats* stats);
+/* Same as rt_render but accum_rgb is DEVICE memory on the scene's device; the launches are
+ * enqueued on `stream` (a hipStream_t, may be null).  If accumulate != 0 the samples are
+ * added to the buffer's contents, else the buffer is overwritten.  If stats is non-null the
+ * call synchronises the stream before returning.  This is what the multi-GPU path uses:
+ * each rank renders its sample range, then one RCCL sum all-reduce merges the buffers.    */
+int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+                     float* accum_rgb_device, int accumulate, void* stream, rt_stats* stats);
+
+/* Replaces: `pixel_color /= spp; pixel_from_color(pixel_color)` (main.rs:167-168, 51-63):
+ * gamma 2, clamp [0, 0.9999], ×256, truncate; NaN → 0 like Rust's saturating `as u8`.    */
+void rt_tonemap(const float* accum_rgb, uint64_t n_pixels, uint64_t spp, uint8_t* rgb8);
+int rt_tonemap_device(int device, const float* accum_rgb_device, uint64_t n_pixels, uint64_t spp,
+                      uint8_t* rgb8_device, void* stream);
+
+/* Device-side evaluation of the two functions the reference's own tests pin
+ * (hittable.rs:547-556 get_sphere_uv; alias.rs:188-215 quaternion rotate), so the KATs can
+ * be run against the kernels' code, not only against the oracle.  n items each.          */
+int rt_kat_sphere_uv(int device, uint32_t n, const double* p /*[n][3]*/, double* uv /*[n][2]*/, int use_f32);
+int rt_kat_rotate(int device, uint32_t n, const double* angle_rad, const double* axis /*[n][3]*/,
+                  const double* v /*[n][3]*/, double* out /*[n][3]*/, int use_f32);
+int rt_kat_philox(int device, uint32_t n, const uint32_t* ctr /*[n][4]*/, const uint32_t* key /*[n][2]*/,
+                  uint32_t* out /*[n][4]*/);
+
+int rt_device_count(void);
+uint32_t rt_abi_version(void);
+const char* rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_H */

@@ -1,0 +1,71 @@
+/*
+ * rt_host.h — C ABI of librt_host.so: the host layer ABOVE include/rt.h.
+ *
+ * The reference is a Rust binary; rustc/cargo are absent from this image, so the host side
+ * is C++17 (raytracer_amd/csrc/host/) and mirrors the reference's own construction API
+ * (hittable.rs:113-157, material.rs:32-55, texture.rs:16-31, cam.rs:26-61, scenes.rs,
+ * main.rs:107-177).  These entry points are what Python (ctypes) and the bench call; a Rust
+ * host would bind include/rt.h directly and keep its own scenes.rs.
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rth_scene rth_scene; /* a flattened scene + its camera, host memory only */
+
+typedef struct rth_scene_opts {
+  int32_t scene_id;        /* main.rs:117-124: 0 random, 1 two_spheres, 2 earth, 3 simple_light, 4 cube_scene,
+                              other small_scene; plus 6 cornell_box, 7 bvh_stress, 8 final_scene */
+  int32_t rotate_bbox;     /* -1 scene default, 0 reference (Q3), 1 correct */
+  double aspect_ratio;     /* main.rs:41-42 */
+  uint64_t scene_seed;     /* scenes.rs:64 uses 5 */
+  uint64_t bvh_seed;       /* split-axis stream (hittable.rs:161 is unseeded in the reference) */
+  uint32_t n;              /* scene 7: number of random spheres */
+  uint32_t tex_width, tex_height;
+  const uint8_t* texels;   /* decoded assets/earthmap.jpg, RGB8 row-major (scenes 2, 4, 8) */
+} rth_scene_opts;
+
+/* Replaces main.rs:117-150: scene function, Hittable::new_bvh, lights fold, Camera::new. */
+int rth_scene_build(const rth_scene_opts* opts, rth_scene** out);
+void rth_scene_free(rth_scene* scene);
+const rt_scene_desc* rth_scene_desc(const rth_scene* scene);
+const rt_camera* rth_scene_camera(const rth_scene* scene);
+uint32_t rth_scene_object_count(const rth_scene* scene);
+uint32_t rth_scene_bvh_calls(const rth_scene* scene);
+
+/* Replaces Camera::new (cam.rs:26-61). */
+int rth_camera_new(const double lookfrom[3], const double lookat[3], const double vup[3], double vfov,
+                   double aspect_ratio, double aperture, double focus_dist, double time_open, double time_close,
+                   rt_camera* out);
+
+typedef struct rth_render_opts {   /* = struct Opts, main.rs:28-49, plus what main() hard-codes */
+  rth_scene_opts scene;
+  uint32_t image_width;            /* -i, default 1200 */
+  uint32_t samples_per_pixel;      /* --samples-per-pixel, default 500 */
+  uint32_t max_depth;              /* --max-depth, default 5 */
+  int32_t device;
+  uint64_t seed;
+} rth_render_opts;
+
+/* Replaces main() from "World" to the put_pixel loop (main.rs:116-174): builds the scene,
+ * renders on the GPU through include/rt.h, tonemaps.  rgb8 is [h][w][3] with
+ * h = trunc(image_width / aspect_ratio) (main.rs:112); accum (may be null) receives the
+ * per-pixel radiance SUM.  *height_out receives h.                                        */
+int rth_render(const rth_render_opts* opts, uint8_t* rgb8, float* accum, uint32_t* height_out, rt_stats* stats);
+uint32_t rth_image_height(uint32_t image_width, double aspect_ratio); /* main.rs:112 */
+
+/* Host-side known-answer hooks for the two functions the reference's tests pin. */
+void rth_rotate(double angle_rad, const double axis[3], const double v[3], double out[3]);
+int rth_bvh_axis(uint64_t bvh_seed, uint32_t call);
+
+const char* rth_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HOST_H */

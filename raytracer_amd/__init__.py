@@ -1,0 +1,9 @@
+"""raytracer_amd — the per-pixel path-tracing hot path of dr-BEat/raytracer as gfx950 HIP
+kernels behind a C ABI (include/rt.h), with a C++17 host layer (include/rt_host.h).
+
+Importing this package loads the in-tree native libraries and raises if they are missing:
+there is no CPU fallback."""
+from . import _ffi
+from .api import (SCENE_IDS, DeviceScene, HostScene, image_height, load_earthmap, render, tonemap)
+
+__all__ = ["SCENE_IDS", "DeviceScene", "HostScene", "image_height", "load_earthmap", "render", "tonemap", "_ffi"]

@@ -1,0 +1,205 @@
+"""Python face of the host layer: the reference's `Opts` / `main()` surface (main.rs:28-49,
+107-177) over the native libraries.  numpy in, numpy out; torch is only used by
+raytracer_amd.distributed for device buffers and the RCCL all-reduce."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _ffi as F
+
+_ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+SCENE_IDS = {
+    "random_scene": 0, "two_spheres": 1, "earth": 2, "simple_light": 3, "cube_scene": 4, "small_scene": 5,
+    "cornell_box": 6, "bvh_stress": 7, "final_scene": 8,
+}
+_NEEDS_EARTHMAP = (2, 4, 8)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def load_earthmap():
+    """assets/earthmap.jpg of the reference, decoded once to RGB8 (texture.rs:29-30 decodes with the
+    `image` crate; here the decode was done offline, see tests/golden/make_fixtures.py)."""
+    with np.load(os.path.join(_ASSETS, "earthmap_rgb8.npz")) as z:
+        return np.ascontiguousarray(z["rgb8"])
+
+
+def image_height(image_width, aspect_ratio):
+    """main.rs:112: `(image_width as f64 / aspect_ratio) as u32` (truncation)."""
+    return int(F.host.rth_image_height(int(image_width), float(aspect_ratio)))
+
+
+class HostScene:
+    """main.rs:117-150 — scene function, world BVH, lights fold, camera — flattened (host memory)."""
+
+    def __init__(self, scene, aspect_ratio, scene_seed=5, bvh_seed=7, n=0, rotate_bbox=-1, texels=None):
+        scene_id = SCENE_IDS[scene] if isinstance(scene, str) else int(scene)
+        if texels is None and scene_id in _NEEDS_EARTHMAP:
+            texels = load_earthmap()
+        o = F.RthSceneOpts()
+        o.scene_id = scene_id
+        o.rotate_bbox = rotate_bbox
+        o.aspect_ratio = aspect_ratio
+        o.scene_seed = scene_seed
+        o.bvh_seed = bvh_seed
+        o.n = n
+        self._texels = None
+        if texels is not None:
+            self._texels = np.ascontiguousarray(texels, dtype=np.uint8)
+            o.tex_height, o.tex_width = self._texels.shape[:2]
+            o.texels = _ptr(self._texels)
+        self.opts = o
+        h = C.c_void_p()
+        F.check_host(F.host.rth_scene_build(C.byref(o), C.byref(h)))
+        self._h = h
+        self.desc = F.host.rth_scene_desc(h).contents
+        self.camera = F.host.rth_scene_camera(h).contents
+        self.n_objects = int(F.host.rth_scene_object_count(h))
+        self.bvh_calls = int(F.host.rth_scene_bvh_calls(h))
+        self.scene_id = scene_id
+        self.aspect_ratio = aspect_ratio
+
+    def close(self):
+        if getattr(self, "_h", None):
+            F.host.rth_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # numpy copies of the flat arrays (for tests and inspection)
+    def _arr(self, ptr, shape, dtype):
+        n = int(np.prod(shape))
+        if n == 0:
+            return np.zeros(shape, dtype=dtype)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).reshape(shape).copy()
+
+    def nodes(self):
+        d = self.desc
+        return (self._arr(d.node_box, (d.n_nodes, 6), np.float64), self._arr(d.node_left, (d.n_nodes,), np.uint32),
+                self._arr(d.node_right, (d.n_nodes,), np.uint32), int(d.root))
+
+    def leaf_object(self, ref):
+        """world-level object id behind a typed leaf ref"""
+        d = self.desc
+        kind, idx = (ref >> 28) & 7, ref & 0x0FFFFFFF
+        arr = [d.sphere_object, d.msphere_object, d.cube_object, d.complex_object][kind]
+        return int(arr[idx])
+
+    def camera_array(self):
+        c = self.camera
+        return np.array(list(c.origin) + list(c.lower_left) + list(c.horizontal) + list(c.vertical) + list(c.u)
+                        + list(c.v) + [c.lens_radius, c.time_open, c.time_close])
+
+
+class DeviceScene:
+    """An rt_scene: the flat scene resident in one GPU's HBM."""
+
+    def __init__(self, host_scene, device=0):
+        self.host = host_scene
+        self.device = device
+        h = C.c_void_p()
+        F.check_hip(F.hip.rt_scene_create(device, C.byref(host_scene.desc), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            F.hip.rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def primary_hits(self, width, height, seed=1, time=0.0, f64=False, camera=None):
+        dt = np.float64 if f64 else np.float32
+        ids = np.zeros((height, width), dtype=np.uint32)
+        t = np.zeros((height, width), dtype=dt)
+        nrm = np.zeros((height, width, 3), dtype=dt)
+        uv = np.zeros((height, width, 2), dtype=dt)
+        ff = np.zeros((height, width), dtype=np.uint8)
+        fn = F.hip.rt_primary_hits_f64 if f64 else F.hip.rt_primary_hits
+        cam = camera if camera is not None else self.host.camera
+        F.check_hip(fn(self._h, C.byref(cam), width, height, seed, time, _ptr(ids), _ptr(t), _ptr(nrm), _ptr(uv),
+                       _ptr(ff)))
+        return ids, t, nrm, uv, ff
+
+    def _params(self, width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats):
+        p = F.RtParams()
+        p.width, p.height, p.spp, p.max_depth = width, height, spp, max_depth
+        p.seed, p.sample_offset = seed, sample_offset
+        p.spp_per_launch = spp_per_launch
+        p.flags = F.RT_FLAG_STATS if stats else 0
+        return p
+
+    def render(self, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0, stats=False,
+               f64=False, camera=None):
+        """The render closure main.rs:154-167 for every pixel: returns (accum SUM [h][w][3], stats dict)."""
+        p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats)
+        accum = np.zeros((height, width, 3), dtype=np.float64 if f64 else np.float32)
+        st = F.RtStats()
+        fn = F.hip.rt_render_f64 if f64 else F.hip.rt_render
+        cam = camera if camera is not None else self.host.camera
+        F.check_hip(fn(self._h, C.byref(cam), C.byref(p), _ptr(accum), C.byref(st)))
+        return accum, st.as_dict()
+
+    def render_device(self, accum_ptr, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0,
+                      accumulate=False, stream=None, want_stats=True, stats=False, camera=None):
+        """Same, into DEVICE memory (accum_ptr = raw device address of a float32 [h][w][3] buffer)."""
+        p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats)
+        st = F.RtStats()
+        cam = camera if camera is not None else self.host.camera
+        F.check_hip(F.hip.rt_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(accum_ptr),
+                                           1 if accumulate else 0, C.c_void_p(stream or 0),
+                                           C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None
+
+
+def tonemap(accum, spp):
+    """main.rs:167-168 + 51-63: mean, gamma 2, clamp, quantise."""
+    accum = np.ascontiguousarray(accum, dtype=np.float32)
+    out = np.zeros(accum.shape, dtype=np.uint8)
+    F.hip.rt_tonemap(_ptr(accum), accum.size // 3, spp, _ptr(out))
+    return out
+
+
+def render(scene=3, image_width=1200, aspect_ratio=1.5, samples_per_pixel=500, max_depth=5, device=0, seed=1,
+           scene_seed=5, bvh_seed=7, n=0, texels=None):
+    """main() of the reference (same option names and defaults as `struct Opts`, main.rs:28-49) minus
+    the PNG save: returns (rgb8 [h][w][3], accum SUM float32 [h][w][3], stats dict)."""
+    scene_id = SCENE_IDS[scene] if isinstance(scene, str) else int(scene)
+    if texels is None and scene_id in _NEEDS_EARTHMAP:
+        texels = load_earthmap()
+    o = F.RthRenderOpts()
+    o.scene.scene_id = scene_id
+    o.scene.rotate_bbox = -1
+    o.scene.aspect_ratio = aspect_ratio
+    o.scene.scene_seed = scene_seed
+    o.scene.bvh_seed = bvh_seed
+    o.scene.n = n
+    keep = None
+    if texels is not None:
+        keep = np.ascontiguousarray(texels, dtype=np.uint8)
+        o.scene.tex_height, o.scene.tex_width = keep.shape[:2]
+        o.scene.texels = _ptr(keep)
+    o.image_width = image_width
+    o.samples_per_pixel = samples_per_pixel
+    o.max_depth = max_depth
+    o.device = device
+    o.seed = seed
+    h = image_height(image_width, aspect_ratio)
+    rgb8 = np.zeros((h, image_width, 3), dtype=np.uint8)
+    accum = np.zeros((h, image_width, 3), dtype=np.float32)
+    st = F.RtStats()
+    hh = C.c_uint32()
+    F.check_host(F.host.rth_render(C.byref(o), _ptr(rgb8), _ptr(accum), C.byref(hh), C.byref(st)))
+    return rgb8, accum, st.as_dict()

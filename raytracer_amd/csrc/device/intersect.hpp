@@ -1,0 +1,359 @@
+// Flattened-BVH traversal and primitive intersection: the device form of Hittable::hit
+// (hittable.rs:208-415) and AxisAlignedBoundingBox::hit (aabb.rs:17-34).
+//
+// The reference recurses (Bvh arm, hittable.rs:400-412): box test, left child, then the right
+// child clipped to the left hit's t, right wins only if strictly closer.  Every arm returns
+// t <= the t_max it was given, so that recursion is equivalent to an iterative left-first
+// DFS with a LIFO stack, ONE running `closest`, node boxes tested against (t_min, closest),
+// and replacement only on strictly smaller t: same nodes visited, same primitives tested
+// with the same bounds, same medium draws in the same order, same winner on ties.
+//
+// Traversal keeps only (t, leaf ref) per candidate; the full HitRecord (p, normal, uv,
+// front_face — hittable.rs:17-40) is rebuilt once, for the winner, by make_hit_record().
+#pragma once
+#include "philox.hpp"
+#include "scene_view.hpp"
+
+namespace rt {
+
+template <bool STATS> struct Cnt {
+  uint32_t v[STATS ? ST_COUNT : 1];
+  RT_DEV void clear() {
+#pragma unroll
+    for (int i = 0; i < (STATS ? (int)ST_COUNT : 1); ++i) v[i] = 0;
+  }
+  template <int I> RT_DEV void inc() {
+    if constexpr (I == ST_RAYS)
+      ++v[0];
+    else if constexpr (STATS)
+      ++v[I];
+  }
+};
+
+template <typename R> struct RayT {
+  Vec3<R> o, d;
+  R time;
+};
+
+// ---- aabb.rs:17-34, with inv_d hoisted out of the per-node loop (the reference multiplies
+// by inv_d = 1/d, so hoisting is bit-identical) -------------------------------------------
+template <typename R>
+RT_DEV bool slab_hit(const R* lo, const R* hi, Vec3<R> o, Vec3<R> inv_d, R& t_min, R& t_max) {
+  {
+    R t0 = (lo[0] - o.x) * inv_d.x, t1 = (hi[0] - o.x) * inv_d.x;
+    if (inv_d.x < R(0)) { R s = t0; t0 = t1; t1 = s; }
+    t_min = rmax(t0, t_min);
+    t_max = rmin(t1, t_max);
+    if (t_max <= t_min) return false;
+  }
+  {
+    R t0 = (lo[1] - o.y) * inv_d.y, t1 = (hi[1] - o.y) * inv_d.y;
+    if (inv_d.y < R(0)) { R s = t0; t0 = t1; t1 = s; }
+    t_min = rmax(t0, t_min);
+    t_max = rmin(t1, t_max);
+    if (t_max <= t_min) return false;
+  }
+  {
+    R t0 = (lo[2] - o.z) * inv_d.z, t1 = (hi[2] - o.z) * inv_d.z;
+    if (inv_d.z < R(0)) { R s = t0; t0 = t1; t1 = s; }
+    t_min = rmax(t0, t_min);
+    t_max = rmin(t1, t_max);
+    if (t_max <= t_min) return false;
+  }
+  return true;
+}
+
+// ---- hittable.rs:257-276 (Sphere) -------------------------------------------------------
+template <typename R>
+RT_DEV bool sphere_t(Vec3<R> o, Vec3<R> d, R a, Vec3<R> c, R radius, R t_min, R t_max, R& t_out) {
+  Vec3<R> oc = o - c;
+  R half_b = dot(oc, d);
+  R cc = sqrlen(oc) - radius * radius;
+  R disc = half_b * half_b - a * cc;
+  if (disc < R(0)) return false;
+  R sqrtd = rroot(disc);
+  R root = (-half_b - sqrtd) / a;
+  if (root < t_min || root > t_max) {
+    root = (-half_b + sqrtd) / a;
+    if (root < t_min || root > t_max) return false;
+  }
+  t_out = root;
+  return true;
+}
+// f32 production form.  The reference computes in f64; in f32 the two subtractions
+// |oc|^2 - r^2 and half_b^2 - a*c cancel catastrophically for the r = 1000 ground spheres
+// (scenes.rs:59,148) and for small far spheres, which would break the 1e-5 bound on t and
+// normals.  The inputs stay f32; only the cancelling dot products are carried in f64
+// (vector f64 runs at half the f32 rate on gfx950), then everything returns to f32.
+template <>
+RT_DEV bool sphere_t<float>(Vec3<float> o, Vec3<float> d, float a, Vec3<float> c, float radius, float t_min,
+                            float t_max, float& t_out) {
+  const double ocx = (double)o.x - (double)c.x, ocy = (double)o.y - (double)c.y, ocz = (double)o.z - (double)c.z;
+  const double dx = d.x, dy = d.y, dz = d.z;
+  const double half_b = ocx * dx + ocy * dy + ocz * dz;
+  const double cc = ocx * ocx + ocy * ocy + ocz * ocz - (double)radius * (double)radius;
+  const double a64 = dx * dx + dy * dy + dz * dz;
+  const double disc = half_b * half_b - a64 * cc;
+  if (disc < 0.0) return false;
+  const double sqrtd = (double)sqrtf((float)disc);
+  float root = (float)(-half_b - sqrtd) / a;
+  if (root < t_min || root > t_max) {
+    root = (float)(-half_b + sqrtd) / a;
+    if (root < t_min || root > t_max) return false;
+  }
+  t_out = root;
+  return true;
+}
+
+// outward normal (p - c) / radius, hittable.rs:278; the f32 form builds p - c as
+// (o - c) + t d with o - c rounded once, instead of rounding p first.
+template <typename R>
+RT_DEV Vec3<R> sphere_outward(Vec3<R> o, Vec3<R> d, R t, Vec3<R> p, Vec3<R> c, R radius) {
+  return (p - c) / radius;
+}
+template <>
+RT_DEV Vec3<float> sphere_outward<float>(Vec3<float> o, Vec3<float> d, float t, Vec3<float> p, Vec3<float> c,
+                                         float radius) {
+  Vec3<float> oc((float)((double)o.x - (double)c.x), (float)((double)o.y - (double)c.y),
+                 (float)((double)o.z - (double)c.z));
+  return (oc + t * d) / radius;
+}
+
+// hittable.rs:66-72
+template <typename R> RT_DEV Vec3<R> moving_center(const MSphere<R>& m, R time) {
+  Vec3<R> c0(m.c0[0], m.c0[1], m.c0[2]), c1(m.c1[0], m.c1[1], m.c1[2]);
+  return c0 + ((time - m.t0) / (m.t1 - m.t0)) * (c1 - c0);
+}
+
+// One simple primitive (SPHERE / MSPHERE / CUBE) against a ray in that primitive's frame.
+template <typename R, bool STATS>
+RT_DEV bool prim_t(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, Vec3<R> inv_d, R a, R t_min,
+                   R t_max, R& t_out, Cnt<STATS>& cnt) {
+  uint32_t kind = ref_kind(ref), idx = ref_index(ref);
+  if (kind == LEAF_SPHERE) {
+    cnt.template inc<ST_SPHERE_TESTS>();
+    Real4<R> s = sc.spheres[idx];
+    bool h = sphere_t(r.o, r.d, a, Vec3<R>(s.x, s.y, s.z), s.w, t_min, t_max, t_out);
+    if (h) cnt.template inc<ST_SPHERE_HITS>();
+    return h;
+  } else if (kind == LEAF_MSPHERE) {
+    cnt.template inc<ST_SPHERE_TESTS>();
+    MSphere<R> m = sc.mspheres[idx];
+    bool h = sphere_t(r.o, r.d, a, moving_center(m, r.time), m.radius, t_min, t_max, t_out);
+    if (h) cnt.template inc<ST_SPHERE_HITS>();
+    return h;
+  } else {  // LEAF_CUBE: hittable.rs:210-229 — returns the ENTRY t only (running t_min, Q2)
+    cnt.template inc<ST_CUBE_TESTS>();
+    Cube<R> c = sc.cubes[idx];
+    R lo = t_min, hi = t_max;
+    if (!slab_hit(c.p0, c.p1, r.o, inv_d, lo, hi)) return false;
+    cnt.template inc<ST_CUBE_HITS>();
+    t_out = lo;
+    return true;
+  }
+}
+
+template <typename R> RT_DEV Vec3<R> inverse3(Vec3<R> d) { return {R(1) / d.x, R(1) / d.y, R(1) / d.z}; }
+
+// A chain of Translate / Rotate / ConstantMedium wrappers around one primitive
+// (hittable.rs:319-386).  All wrappers are rigid, so t is the same in every frame.
+template <typename R, bool STATS>
+RT_DEV bool complex_t(const SceneView<R>& sc, uint32_t idx, const RayT<R>& r, R t_min, R t_max, Rng& rng,
+                      R& t_out, Cnt<STATS>& cnt) {
+  Complex cx = sc.complexes[idx];
+  RayT<R> lr = r;
+  Vec3<R> dm = r.d;  // direction in the medium's frame
+  R neg_inv_density = R(0);
+  for (uint32_t k = 0; k < cx.op_count; ++k) {
+    uint32_t tag = sc.op_tag[cx.op_first + k];
+    Op<R> op = sc.ops[cx.op_first + k];
+    if (tag == OP_TRANSLATE) {  // hittable.rs:365
+      cnt.template inc<ST_TRANSLATE>();
+      lr.o = lr.o - Vec3<R>(op.d[0], op.d[1], op.d[2]);
+    } else if (tag == OP_ROTATE) {  // hittable.rs:375-377
+      cnt.template inc<ST_ROTATE>();
+      Quat<R> q{op.d[0], op.d[1], op.d[2], op.d[3]};
+      lr.o = qrotate(lr.o, q);
+      lr.d = qrotate(lr.d, q);
+    } else {
+      cnt.template inc<ST_MEDIUM>();
+      dm = lr.d;
+      neg_inv_density = op.d[0];
+    }
+  }
+  Vec3<R> inv_d = inverse3(lr.d);
+  R a = sqrlen(lr.d);
+  if (cx.medium_pos == REF_NONE) return prim_t(sc, cx.body, lr, inv_d, a, t_min, t_max, t_out, cnt);
+
+  // hittable.rs:319-349
+  R t1, t2;
+  cnt.template inc<ST_MEDIUM_PROBES>();
+  if (!prim_t(sc, cx.body, lr, inv_d, a, -Consts<R>::inf, Consts<R>::inf, t1, cnt)) return false;
+  cnt.template inc<ST_MEDIUM_PROBES>();
+  if (!prim_t(sc, cx.body, lr, inv_d, a, t1 + R(0.0001), Consts<R>::inf, t2, cnt)) return false;
+  t1 = rmax(t1, t_min);
+  t2 = rmin(t2, t_max);
+  if (t1 >= t2) return false;
+  t1 = rmax(t1, R(0));
+  R ray_length = length(dm);
+  R distance_inside_boundary = (t2 - t1) * ray_length;
+  R hit_distance = neg_inv_density * rlog(rng.next<R>());
+  if (hit_distance > distance_inside_boundary) return false;
+  t_out = t1 + hit_distance / ray_length;
+  return true;
+}
+
+// world.hit(r, t_min, +inf) — hittable.rs:400-412 as an iterative DFS.  `stack` is this
+// lane's column of the LDS stack: entry i lives at stack[i * stride].
+template <typename R, bool STATS>
+RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, uint32_t* stack,
+                     uint32_t stride, R& closest, uint32_t& best, Cnt<STATS>& cnt) {
+  closest = Consts<R>::inf;
+  best = REF_NONE;
+  uint32_t cur = sc.root;
+  if (cur == REF_NONE) return;
+  const Vec3<R> inv_d = inverse3(r.d);
+  const R a = sqrlen(r.d);
+  uint32_t sp = 0;
+  for (;;) {
+    if (!(cur & REF_LEAF)) {
+      cnt.template inc<ST_NODES>();
+      Node<R> n = sc.nodes[cur];
+      R lo = t_min, hi = closest;
+      if (slab_hit(n.lo, n.hi, r.o, inv_d, lo, hi)) {
+        stack[sp * stride] = n.right;
+        ++sp;
+        cur = n.left;
+        continue;
+      }
+    } else {
+      R t;
+      bool h;
+      if (ref_kind(cur) == LEAF_COMPLEX)
+        h = complex_t(sc, ref_index(cur), r, t_min, closest, rng, t, cnt);
+      else
+        h = prim_t(sc, cur, r, inv_d, a, t_min, closest, t, cnt);
+      if (h && t < closest) {
+        closest = t;
+        best = cur;
+      }
+    }
+    if (sp == 0) break;
+    --sp;
+    cur = stack[sp * stride];
+  }
+}
+
+// ---- the winner's HitRecord (hittable.rs:17-40) -------------------------------------------
+template <typename R> struct HitRec {
+  Vec3<R> p, normal;
+  Vec2<R> uv;
+  bool front_face;
+  uint32_t material, object;
+};
+
+template <typename R>
+RT_DEV void face_normal(Vec3<R> d, Vec3<R> outward, HitRec<R>& h) {  // hittable.rs:26-36
+  h.front_face = dot(d, outward) < R(0);
+  h.normal = h.front_face ? outward : -outward;
+}
+
+template <typename R>
+RT_DEV void prim_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, R t, HitRec<R>& h) {
+  uint32_t kind = ref_kind(ref), idx = ref_index(ref);
+  h.p = r.o + t * r.d;  // Ray::at, ray.rs:19-21
+  if (kind == LEAF_CUBE) {  // hittable.rs:229-255
+    Cube<R> c = sc.cubes[idx];
+    Attr at = sc.cube_attr[idx];
+    h.material = at.material;
+    h.object = at.object;
+    Vec3<R> p0(c.p0[0], c.p0[1], c.p0[2]), p1(c.p1[0], c.p1[1], c.p1[2]);
+    Vec3<R> rel = (h.p - p0) / (p1 - p0);
+    const R eps = R(0.002);
+    Vec3<R> n;
+    if (rel.x < eps)
+      n = Vec3<R>(1, 0, 0);
+    else if (rel.x > R(1) - eps)
+      n = Vec3<R>(-1, 0, 0);
+    else if (rel.y < eps)
+      n = Vec3<R>(0, 1, 0);
+    else if (rel.y > R(1) - eps)
+      n = Vec3<R>(0, -1, 0);
+    else if (rel.z < eps)
+      n = Vec3<R>(0, 0, 1);
+    else if (rel.z > R(1) - eps)
+      n = Vec3<R>(0, 0, -1);
+    else
+      n = normalize(Vec3<R>(R(0.5), R(0.5), R(0.5)));
+    R az = rabs(n.z), ax = rabs(n.x), ay = rabs(n.y);
+    h.uv.x = rel.x * az + rel.y * ax + rel.x * ay;
+    h.uv.y = rel.y * az + rel.z * ax + rel.z * ay;
+    face_normal(r.d, n, h);
+  } else {  // hittable.rs:277-286 / 308-317
+    Vec3<R> c;
+    R radius;
+    Attr at;
+    if (kind == LEAF_SPHERE) {
+      Real4<R> s = sc.spheres[idx];
+      c = Vec3<R>(s.x, s.y, s.z);
+      radius = s.w;
+      at = sc.sphere_attr[idx];
+    } else {
+      MSphere<R> m = sc.mspheres[idx];
+      c = moving_center(m, r.time);
+      radius = m.radius;
+      at = sc.msphere_attr[idx];
+    }
+    h.material = at.material;
+    h.object = at.object;
+    Vec3<R> outward = sphere_outward(r.o, r.d, t, h.p, c, radius);
+    h.uv = get_sphere_uv(outward);
+    face_normal(r.d, outward, h);
+  }
+}
+
+template <typename R>
+RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, R t, HitRec<R>& h) {
+  if (ref_kind(ref) != LEAF_COMPLEX) {
+    prim_record(sc, ref, r, t, h);
+    return;
+  }
+  Complex cx = sc.complexes[ref_index(ref)];
+  RayT<R> lr = r;
+  uint32_t n_outer = cx.medium_pos == REF_NONE ? cx.op_count : cx.medium_pos;
+  for (uint32_t k = 0; k < n_outer; ++k) {
+    uint32_t tag = sc.op_tag[cx.op_first + k];
+    Op<R> op = sc.ops[cx.op_first + k];
+    if (tag == OP_TRANSLATE) {
+      lr.o = lr.o - Vec3<R>(op.d[0], op.d[1], op.d[2]);
+    } else {
+      Quat<R> q{op.d[0], op.d[1], op.d[2], op.d[3]};
+      lr.o = qrotate(lr.o, q);
+      lr.d = qrotate(lr.d, q);
+    }
+  }
+  if (cx.medium_pos == REF_NONE) {
+    prim_record(sc, cx.body, lr, t, h);
+  } else {  // hittable.rs:349-362: arbitrary normal (1,0,0), uv (0,0), in the medium's frame
+    h.p = lr.o + t * lr.d;
+    h.uv.x = R(0);
+    h.uv.y = R(0);
+    face_normal(lr.d, Vec3<R>(1, 0, 0), h);
+    h.material = cx.material;
+  }
+  h.object = cx.object;
+  // unwind the outer wrappers, innermost first (hittable.rs:369-372, 378-385)
+  for (uint32_t k = n_outer; k-- > 0;) {
+    uint32_t tag = sc.op_tag[cx.op_first + k];
+    Op<R> op = sc.ops[cx.op_first + k];
+    if (tag == OP_TRANSLATE) {
+      h.p = h.p + Vec3<R>(op.d[0], op.d[1], op.d[2]);
+    } else {
+      Quat<R> qi = qinvert(Quat<R>{op.d[0], op.d[1], op.d[2], op.d[3]});
+      h.p = qrotate(h.p, qi);
+      h.normal = qrotate(h.normal, qi);
+    }
+  }
+}
+
+}  // namespace rt

@@ -1,0 +1,446 @@
+// The path-tracing megakernel and its helpers: the device form of the render closure
+// (main.rs:154-167), Camera::get_ray (cam.rs:63-71), ray_color (main.rs:65-105),
+// Material::{scatter, scattering_pdf, emit} (material.rs:57-133), PDF::{value, generate}
+// (pdf.rs:13-39), Hittable::{pdf_value, random} (hittable.rs:477-515) and Texture::value
+// (texture.rs:33-69).
+//
+// Execution shape (CDNA4): one 64-lane wavefront owns an 8x8 pixel tile, four waves make a
+// 16x16 workgroup tile.  Each lane runs ONE flat loop whose iteration is one path vertex;
+// a lane whose path ends regenerates its next sample inside the same loop, so lanes drift
+// apart in sample index but stay busy (the recursion of ray_color becomes
+// throughput/radiance registers).  Per-lane BVH stack lives in LDS, column-major by lane.
+#pragma once
+#include "intersect.hpp"
+
+namespace rt {
+
+constexpr int BLOCK = 256;
+
+// ---- texture.rs:33-69 ---------------------------------------------------------------------
+template <typename R>
+RT_DEV Vec3<R> texture_value(const SceneView<R>& sc, uint32_t idx, Vec2<R> uv, Vec3<R> p, Vec3<R> normal) {
+  for (;;) {
+    Texture<R> t = sc.textures[idx];
+    if (t.tag == TEX_CHECKER) {
+      const R scale = R(10);
+      R sines = rsin(scale * p.x) * rsin(scale * p.y) * rsin(scale * p.z);
+      idx = sines < R(0) ? t.odd : t.even;
+      continue;
+    }
+    if (t.tag == TEX_SOLID) return Vec3<R>(t.color[0], t.color[1], t.color[2]);
+    if (t.tag == TEX_IMAGE) {
+      R u = rmin(rmax(uv.x, R(0)), R(1));
+      R v = rmin(rmax(uv.y, R(0)), R(1));
+      v = R(1) - v;
+      uint32_t x = (uint32_t)(u * (R)t.width);
+      uint32_t y = (uint32_t)(v * (R)t.height);
+      x = x < t.width - 1 ? x : t.width - 1;
+      y = y < t.height - 1 ? y : t.height - 1;
+      const uint8_t* px = sc.texels + t.texel_offset + 3ull * ((uint64_t)y * t.width + x);
+      const R color_scale = R(1) / R(255);
+      return Vec3<R>((R)px[0] * color_scale, (R)px[1] * color_scale, (R)px[2] * color_scale);
+    }
+    if (t.tag == TEX_NORMAL) return Vec3<R>(rabs(normal.x), rabs(normal.y), rabs(normal.z));
+    return Vec3<R>(uv.x, uv.y, R(0));  // TEX_UV
+  }
+}
+
+// ---- alias.rs:44-94 -------------------------------------------------------------------------
+template <typename R> RT_DEV Vec3<R> random_in_unit_sphere(Rng& rng) {
+  for (;;) {
+    R a = rng.range<R>(R(-1), R(1));
+    R b = rng.range<R>(R(-1), R(1));
+    R c = rng.range<R>(R(-1), R(1));
+    Vec3<R> p(a, b, c);
+    if (sqrlen(p) < R(1)) return p;
+  }
+}
+template <typename R> RT_DEV Vec3<R> random_in_unit_disk(Rng& rng) {
+  for (;;) {
+    R a = rng.range<R>(R(-1), R(1));
+    R b = rng.range<R>(R(-1), R(1));
+    Vec3<R> p(a, b, R(0));
+    if (sqrlen(p) < R(1)) return p;
+  }
+}
+template <typename R> RT_DEV Vec3<R> random_cosine_direction(Rng& rng) {
+  R r1 = rng.next<R>();
+  R r2 = rng.next<R>();
+  R z = rroot(R(1) - r2);
+  R phi = R(2) * Consts<R>::pi * r1;
+  R x = rcos(phi) * rroot(r2);
+  R y = rsin(phi) * rroot(r2);
+  return Vec3<R>(x, y, z);
+}
+template <typename R> RT_DEV Vec3<R> random_to_sphere(Rng& rng, R radius, R distance_squared) {
+  R r1 = rng.next<R>();
+  R r2 = rng.next<R>();
+  R z = R(1) + r2 * (rroot(R(1) - radius * radius / distance_squared) - R(1));
+  R phi = R(2) * Consts<R>::pi * r1;
+  R x = rcos(phi) * rroot(R(1) - z * z);
+  R y = rsin(phi) * rroot(R(1) - z * z);
+  return Vec3<R>(x, y, z);
+}
+
+// ---- hittable.rs:477-515 on the flattened light list ----------------------------------------
+template <typename R> RT_DEV Vec3<R> light_random_one(const Light<R>& l, Vec3<R> origin, Rng& rng) {
+  if (l.tag != LIGHT_SPHERE) return Vec3<R>(1, 0, 0);
+  Vec3<R> direction = Vec3<R>(l.c[0], l.c[1], l.c[2]) - origin;
+  R distance_squared = sqrlen(direction);
+  ONB<R> uvw = ONB<R>::from_w(direction);
+  return uvw.local(random_to_sphere<R>(rng, l.radius, distance_squared));
+}
+template <typename R> RT_DEV Vec3<R> lights_random(const SceneView<R>& sc, Vec3<R> origin, Rng& rng) {
+  uint32_t i = 0;
+  if (sc.lights_kind == LIGHTS_LIST) i = rng.below(sc.n_lights);  // list.choose()
+  return light_random_one(sc.lights[i], origin, rng);
+}
+template <typename R, bool STATS>
+RT_DEV R light_pdf_one(const Light<R>& l, Vec3<R> origin, Vec3<R> direction, Cnt<STATS>& cnt) {
+  if (l.tag != LIGHT_SPHERE) return R(0);
+  cnt.template inc<ST_LIGHT_PROBES>();
+  cnt.template inc<ST_SPHERE_TESTS>();
+  Vec3<R> c(l.c[0], l.c[1], l.c[2]);
+  R t;
+  if (!sphere_t(origin, direction, sqrlen(direction), c, l.radius, R(0), Consts<R>::inf, t)) return R(0);
+  cnt.template inc<ST_SPHERE_HITS>();
+  R cos_theta_max = rroot(R(1) - l.radius * l.radius / sqrlen(c - origin));
+  R solid_angle = R(2) * Consts<R>::pi * (R(1) - cos_theta_max);
+  return R(1) / solid_angle;
+}
+template <typename R, bool STATS>
+RT_DEV R lights_pdf(const SceneView<R>& sc, Vec3<R> origin, Vec3<R> direction, Cnt<STATS>& cnt) {
+  if (sc.lights_kind == LIGHTS_SINGLE) return light_pdf_one(sc.lights[0], origin, direction, cnt);
+  R weight = R(1) / (R)sc.n_lights;
+  R sum = R(0);
+  for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf_one(sc.lights[i], origin, direction, cnt);
+  return sum;
+}
+
+// material.rs:128-133
+template <typename R> RT_DEV R reflectance(R cosine, R ref_idx) {
+  R r0 = (R(1) - ref_idx) / (R(1) + ref_idx);
+  r0 = r0 * r0;
+  R m = R(1) - cosine;
+  R m2 = m * m;
+  R m4 = m2 * m2;
+  return r0 + (R(1) - r0) * (m4 * m);
+}
+
+// One vertex of ray_color (main.rs:77-102) after the closest hit is known.  Updates the
+// running throughput / radiance, overwrites `ray` with the scattered ray and returns true if
+// the path continues.
+template <typename R, bool STATS>
+RT_DEV bool shade(const SceneView<R>& sc, const HitRec<R>& h, RayT<R>& ray, Vec3<R>& thr, Vec3<R>& L, Rng& rng,
+                  Cnt<STATS>& cnt) {
+  Material<R> m = sc.materials[h.material];
+  if (m.tag == MAT_DIFFUSE_LIGHT) {  // scatter -> None: return emitted (main.rs:101)
+    cnt.template inc<ST_EMITTER>();
+    if (h.front_face) L = L + thr * texture_value(sc, m.texture, h.uv, h.p, h.normal);
+    return false;
+  }
+  if (m.tag == MAT_DIELECTRIC) {  // material.rs:66-87; emitted is dropped (main.rs:81-83)
+    cnt.template inc<ST_SPECULAR>();
+    R ir = m.p[0];
+    R refraction_ratio = h.front_face ? R(1) / ir : ir;
+    Vec3<R> unit_direction = normalize(ray.d);
+    R cos_theta = rmin(dot(-unit_direction, h.normal), R(1));
+    R sin_theta = rroot(R(1) - cos_theta * cos_theta);
+    bool cannot_refract = refraction_ratio * sin_theta > R(1);
+    Vec3<R> direction;
+    if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rng.next<R>())
+      direction = reflect(unit_direction, h.normal);
+    else
+      direction = refract(unit_direction, h.normal, refraction_ratio);
+    ray.o = h.p;
+    ray.d = direction;
+    return true;
+  }
+  if (m.tag == MAT_METAL) {  // material.rs:88-95
+    cnt.template inc<ST_SPECULAR>();
+    Vec3<R> reflected = reflect(normalize(ray.d), h.normal);
+    Vec3<R> direction = reflected + m.p[3] * random_in_unit_sphere<R>(rng);
+    ray.o = h.p;
+    ray.d = direction;
+    thr = thr * Vec3<R>(m.p[0], m.p[1], m.p[2]);
+    return true;
+  }
+  // Lambertian / Isotropic: ScatterRecord::PDF with a cosine PDF (material.rs:59-65, 97-100)
+  cnt.template inc<ST_DIFFUSE>();
+  Vec3<R> attenuation = texture_value(sc, m.texture, h.uv, h.p, h.normal);
+  ONB<R> uvw = ONB<R>::from_w(h.normal);
+  const bool have_lights = sc.lights_kind != LIGHTS_NONE;
+  Vec3<R> direction;
+  bool from_light = false;
+  if (have_lights) from_light = rng.below(2) == 0;  // Mixture[light, cosine].choose(), pdf.rs:36
+  if (from_light)
+    direction = lights_random(sc, h.p, rng);
+  else
+    direction = uvw.local(random_cosine_direction<R>(rng));
+  // pdf.rs:13-31
+  Vec3<R> unit = normalize(direction);
+  R cosine = dot(unit, uvw.w);
+  R cos_pdf = cosine <= R(0) ? R(0) : cosine / Consts<R>::pi;
+  R pdf_value;
+  if (have_lights) {
+    pdf_value = R(0);
+    pdf_value += R(0.5) * lights_pdf(sc, h.p, direction, cnt);
+    pdf_value += R(0.5) * cos_pdf;
+  } else {
+    pdf_value = cos_pdf;
+  }
+  // material.rs:104-116
+  R spdf = R(1);
+  if (m.tag == MAT_LAMBERTIAN) {
+    R c2 = dot(h.normal, unit);
+    spdf = c2 <= R(0) ? R(0) : c2 / Consts<R>::pi;
+  }
+  thr = thr * ((attenuation * spdf) / pdf_value);  // main.rs:93-97
+  ray.o = h.p;
+  ray.d = direction;
+  return true;
+}
+
+// lower_left + s*horizontal + t*vertical - origin (cam.rs:68).  In f32 that sum cancels
+// catastrophically when the camera sits far from the world origin (Cornell: |origin| ~ 900,
+// viewport ~ 7), so the f32 kernels use the host's f64 (lower_left - origin) instead.
+template <typename R> RT_DEV Vec3<R> primary_direction(const CameraView<R>& cam, R s, R t) {
+  if constexpr (sizeof(R) == 4)
+    return cam.ll_rel + s * cam.horizontal + t * cam.vertical;
+  else
+    return cam.lower_left + s * cam.horizontal + t * cam.vertical - cam.origin;
+}
+
+template <typename R> RT_DEV RayT<R> camera_ray(const CameraView<R>& cam, R s, R t, Rng& rng) {  // cam.rs:63-71
+  Vec3<R> rd = cam.lens_radius * random_in_unit_disk<R>(rng);
+  Vec3<R> offset = cam.u * rd.x + cam.v * rd.y;
+  RayT<R> r;
+  r.o = cam.origin + offset;
+  r.d = primary_direction(cam, s, t) - offset;
+  r.time = rng.range<R>(cam.time_open, cam.time_close);
+  return r;
+}
+
+RT_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <bool STATS> RT_DEV void flush_stats(const Cnt<STATS>& cnt, DeviceStats* stats) {
+  constexpr int N = STATS ? (int)ST_COUNT : 1;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    uint32_t s = wave_sum(cnt.v[i]);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats->v[i], (unsigned long long)s);
+  }
+}
+
+RT_DEV void tile_pixel(uint32_t width, uint32_t& px, uint32_t& py) {
+  const uint32_t tiles_x = (width + 15u) / 16u;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  px = (tile % tiles_x) * 16u + (wave & 1u) * 8u + (lane & 7u);
+  py = (tile / tiles_x) * 16u + (wave >> 1) * 8u + (lane >> 3);
+}
+
+struct RenderArgs {
+  uint32_t width, height;
+  uint32_t sample_begin;  // global index of this launch's first sample
+  uint32_t n_samples;
+  uint32_t max_depth;
+  uint32_t accumulate;  // add to accum instead of overwriting it (ignored when splits > 1: always atomic add)
+  uint32_t splits;      // gridDim.y: each block row renders a slice of the launch's samples
+  uint64_t seed;
+};
+
+template <typename R, bool STATS, bool EARLY_EXIT>
+__global__ void __launch_bounds__(BLOCK) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
+                                                       R* __restrict__ accum, DeviceStats* stats) {
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  uint32_t px, py;
+  tile_pixel(a.width, px, py);
+  const bool active = px < a.width && py < a.height;
+  const uint32_t pixel = py * a.width + px;
+
+  Cnt<STATS> cnt;
+  cnt.clear();
+  uint32_t nonfinite = 0;
+  Vec3<R> acc;
+
+  if (active) {
+    const Vec3<R> background(sc.background[0], sc.background[1], sc.background[2]);
+    // this block row's slice of the launch's samples
+    uint32_t s = (uint32_t)(((uint64_t)a.n_samples * blockIdx.y) / a.splits);
+    const uint32_t s_end = (uint32_t)(((uint64_t)a.n_samples * (blockIdx.y + 1)) / a.splits);
+    bool alive = false;
+    RayT<R> ray;
+    Vec3<R> thr, L;
+    uint32_t depth_left = 0, slot = 0;
+    Rng rng;
+    rng.init(a.seed, pixel, 0);
+    for (;;) {
+      if (!alive) {
+        if (s == s_end) break;
+        rng.sample = a.sample_begin + s;
+        ++s;
+        rng.begin(0);
+        R ju = rng.next<R>();
+        R jv = rng.next<R>();
+        R u = ((R)px + ju) / (R)(a.width - 1);                  // main.rs:161
+        R v = ((R)(a.height - py - 1) + jv) / (R)(a.height - 1);  // main.rs:162-163
+        ray = camera_ray(cam, u, v, rng);
+        thr = Vec3<R>(1, 1, 1);
+        L = Vec3<R>(0, 0, 0);
+        depth_left = a.max_depth;
+        slot = 1;
+        alive = true;
+        if (depth_left == 0) {  // main.rs:73-75
+          alive = false;
+          continue;
+        }
+      }
+      rng.begin(slot);
+      cnt.template inc<ST_RAYS>();
+      R t;
+      uint32_t best;
+      traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+      bool cont;
+      if (best == REF_NONE) {  // main.rs:104
+        cnt.template inc<ST_MISSES>();
+        L = L + thr * background;
+        cont = false;
+      } else {
+        cnt.template inc<ST_CLOSEST>();
+        HitRec<R> h;
+        make_hit_record(sc, best, ray, t, h);
+        cont = shade(sc, h, ray, thr, L, rng, cnt);
+      }
+      ++slot;
+      --depth_left;
+      if (depth_left == 0) cont = false;  // the next ray_color call would return 0
+      if (EARLY_EXIT && cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
+      if (!cont) {
+        const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
+        if (!fin) ++nonfinite;
+        // f32 production kernel drops a non-finite sample (DESIGN.md "f32 conditioning");
+        // the f64 audit kernel lets it poison the pixel like the reference does.
+        if (fin || sizeof(R) == 8) acc = acc + L;
+        alive = false;
+      }
+    }
+    R* out = accum + 3ull * pixel;
+    if (a.splits > 1) {
+      atomicAdd(out + 0, acc.x);
+      atomicAdd(out + 1, acc.y);
+      atomicAdd(out + 2, acc.z);
+    } else if (a.accumulate) {
+      out[0] += acc.x;
+      out[1] += acc.y;
+      out[2] += acc.z;
+    } else {
+      out[0] = acc.x;
+      out[1] = acc.y;
+      out[2] = acc.z;
+    }
+  }
+  flush_stats(cnt, stats);
+  uint32_t nf = wave_sum(nonfinite);
+  if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&stats->v[ST_NONFINITE], (unsigned long long)nf);
+}
+
+// world.hit() for the deterministic primary ray of every pixel: parity levels 1-2.
+template <typename R>
+__global__ void __launch_bounds__(BLOCK) primary_kernel(SceneView<R> sc, CameraView<R> cam, uint32_t width,
+                                                        uint32_t height, uint64_t seed, R time,
+                                                        uint32_t* __restrict__ prim_id, R* __restrict__ t_out,
+                                                        R* __restrict__ normal, R* __restrict__ uv,
+                                                        uint8_t* __restrict__ front_face) {
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  uint32_t px, py;
+  tile_pixel(width, px, py);
+  if (px >= width || py >= height) return;
+  const uint32_t pixel = py * width + px;
+  R u = ((R)px + R(0.5)) / (R)(width - 1);
+  R v = ((R)(height - py - 1) + R(0.5)) / (R)(height - 1);
+  RayT<R> ray;
+  ray.o = cam.origin;
+  ray.d = primary_direction(cam, u, v);
+  ray.time = time;
+  Rng rng;
+  rng.init(seed, pixel, 0);
+  rng.begin(1);
+  Cnt<false> cnt;
+  cnt.clear();
+  R t;
+  uint32_t best;
+  traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+  HitRec<R> h;
+  h.object = REF_NONE;
+  h.normal = Vec3<R>(0, 0, 0);
+  h.uv.x = h.uv.y = R(0);
+  h.front_face = false;
+  if (best != REF_NONE) make_hit_record(sc, best, ray, t, h);
+  prim_id[pixel] = h.object;
+  t_out[pixel] = t;
+  normal[3ull * pixel + 0] = h.normal.x;
+  normal[3ull * pixel + 1] = h.normal.y;
+  normal[3ull * pixel + 2] = h.normal.z;
+  if (uv) {
+    uv[2ull * pixel + 0] = h.uv.x;
+    uv[2ull * pixel + 1] = h.uv.y;
+  }
+  if (front_face) front_face[pixel] = h.front_face ? 1 : 0;
+}
+
+#ifdef RT_DEFINE_COMMON
+// main.rs:167-168, 51-63
+__global__ void tonemap_kernel(const float* __restrict__ accum, uint64_t n, float inv_spp, uint8_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float g = sqrtf(accum[i] * inv_spp);
+    uint8_t q = 0;
+    if (g == g) {
+      g = g < 0.0f ? 0.0f : (g > 0.9999f ? 0.9999f : g);
+      q = (uint8_t)(g * 256.0f);
+    }
+    out[i] = q;
+  }
+}
+
+#endif  // RT_DEFINE_COMMON
+
+template <typename R>
+__global__ void kat_sphere_uv_kernel(uint32_t n, const double* p, double* uv) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Vec2<R> r = get_sphere_uv(Vec3<R>((R)p[3 * i], (R)p[3 * i + 1], (R)p[3 * i + 2]));
+  uv[2 * i] = (double)r.x;
+  uv[2 * i + 1] = (double)r.y;
+}
+template <typename R>
+__global__ void kat_rotate_kernel(uint32_t n, const double* angle, const double* axis, const double* v, double* out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Quat<R> q = new_quaternion((R)angle[i], Vec3<R>((R)axis[3 * i], (R)axis[3 * i + 1], (R)axis[3 * i + 2]));
+  Vec3<R> r = qrotate(Vec3<R>((R)v[3 * i], (R)v[3 * i + 1], (R)v[3 * i + 2]), q);
+  out[3 * i] = (double)r.x;
+  out[3 * i + 1] = (double)r.y;
+  out[3 * i + 2] = (double)r.z;
+}
+#ifdef RT_DEFINE_COMMON
+__global__ void kat_philox_kernel(uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  U4 r = philox4x32_10(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], key[2 * i], key[2 * i + 1]);
+  out[4 * i] = r.x;
+  out[4 * i + 1] = r.y;
+  out[4 * i + 2] = r.z;
+  out[4 * i + 3] = r.w;
+}
+#endif  // RT_DEFINE_COMMON
+
+}  // namespace rt

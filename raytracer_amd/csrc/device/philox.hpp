@@ -1,0 +1,87 @@
+// Philox4x32-10 (Salmon et al., SC'11) and the per-path draw streams that replace the
+// reference's `rand` thread_rng (main.rs:161-162, cam.rs:69, alias.rs:41-91,
+// hittable.rs:342,511, pdf.rs:36, material.rs:77).
+//
+// Stream layout: block j of stream (pixel, sample, slot) under key (seed_lo, seed_hi) is
+// philox(ctr = (pixel, sample, slot, j)).  slot 0 = camera ray (jitter u, jitter v, lens
+// disk, shutter time); slot 1+b = bounce b (medium draws during traversal first, then the
+// material / PDF draws).  A slot's first block is generated unconditionally by every lane
+// at the top of a bounce, so the 10 rounds run wave-uniform; further blocks (rejection
+// loops, long medium chains) are drawn on demand.
+#pragma once
+#include "vec.hpp"
+
+namespace rt {
+
+struct U4 {
+  uint32_t x, y, z, w;
+};
+
+RT_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t h0 = __umulhi(M0, c0), l0 = M0 * c0;
+    uint32_t h1 = __umulhi(M1, c2), l1 = M1 * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0;
+    uint32_t n2 = h0 ^ c3 ^ k1;
+    c0 = n0;
+    c1 = l1;
+    c2 = n2;
+    c3 = l0;
+    k0 += W0;
+    k1 += W1;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+template <typename R> RT_DEV R u01(uint32_t x);
+// one 32-bit word per draw in both precisions, so f32 and f64 runs consume the same words
+template <> RT_DEV double u01<double>(uint32_t x) { return (double)x * (1.0 / 4294967296.0); }
+template <> RT_DEV float u01<float>(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+struct Rng {
+  uint32_t k0, k1, pixel, sample, slot, block;
+  uint32_t w0, w1, w2, w3;
+  uint32_t have;
+
+  RT_DEV void init(uint64_t seed, uint32_t pixel_, uint32_t sample_) {
+    k0 = (uint32_t)seed;
+    k1 = (uint32_t)(seed >> 32);
+    pixel = pixel_;
+    sample = sample_;
+    slot = 0;
+    block = 0;
+    have = 0;
+    w0 = w1 = w2 = w3 = 0;
+  }
+  RT_DEV void refill() {
+    U4 r = philox4x32_10(pixel, sample, slot, block, k0, k1);
+    ++block;
+    w0 = r.x;
+    w1 = r.y;
+    w2 = r.z;
+    w3 = r.w;
+    have = 4;
+  }
+  RT_DEV void begin(uint32_t slot_) {
+    slot = slot_;
+    block = 0;
+    refill();
+  }
+  RT_DEV uint32_t next_u32() {
+    if (have == 0) refill();
+    uint32_t r = w0;
+    w0 = w1;
+    w1 = w2;
+    w2 = w3;
+    --have;
+    return r;
+  }
+  template <typename R> RT_DEV R next() { return u01<R>(next_u32()); }
+  template <typename R> RT_DEV R range(R lo, R hi) { return lo + (hi - lo) * next<R>(); }
+  RT_DEV uint32_t below(uint32_t n) { return __umulhi(next_u32(), n); }
+};
+
+}  // namespace rt

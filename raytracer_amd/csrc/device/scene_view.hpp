@@ -1,0 +1,109 @@
+// Device-resident scene: the reference's Hittable / Material / Texture enums
+// (hittable.rs:100-111, material.rs:23-30, texture.rs:7-14) flattened into tagged arrays in
+// HBM.  Hot geometry (what a traversal touches) is split from cold attributes (what only
+// the winning hit touches): a sphere test reads one 16-byte record, a node test 32 bytes.
+#pragma once
+#include "vec.hpp"
+
+namespace rt {
+
+constexpr uint32_t REF_LEAF = 0x80000000u;
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
+constexpr uint32_t LEAF_SPHERE = 0, LEAF_MSPHERE = 1, LEAF_CUBE = 2, LEAF_COMPLEX = 3;
+constexpr uint32_t OP_TRANSLATE = 0, OP_ROTATE = 1, OP_MEDIUM = 2;
+constexpr uint32_t MAT_LAMBERTIAN = 0, MAT_DIELECTRIC = 1, MAT_METAL = 2, MAT_DIFFUSE_LIGHT = 3,
+                   MAT_ISOTROPIC = 4;
+constexpr uint32_t TEX_SOLID = 0, TEX_CHECKER = 1, TEX_IMAGE = 2, TEX_NORMAL = 3, TEX_UV = 4;
+constexpr uint32_t LIGHT_SPHERE = 0, LIGHT_OTHER = 1;
+constexpr uint32_t LIGHTS_NONE = 0, LIGHTS_SINGLE = 1, LIGHTS_LIST = 2;
+
+__host__ __device__ inline uint32_t ref_kind(uint32_t r) { return (r >> 28) & 7u; }
+__host__ __device__ inline uint32_t ref_index(uint32_t r) { return r & 0x0FFFFFFFu; }
+
+template <typename R> struct alignas(4 * sizeof(R)) Real4 {
+  R x, y, z, w;
+};
+
+// BVH node, pre-order.  float: 32 B (two dwordx4 loads); double: 64 B.
+template <typename R> struct Node;
+template <> struct alignas(32) Node<float> {
+  float lo[3];
+  float hi[3];
+  uint32_t left, right;
+};
+template <> struct alignas(64) Node<double> {
+  double lo[3];
+  double hi[3];
+  uint32_t left, right;
+  uint32_t pad[2];
+};
+
+template <typename R> struct alignas(4 * sizeof(R)) MSphere {  // hittable.rs:56-64
+  R c0[3], radius;
+  R c1[3], t0;
+  R t1, pad[3];
+};
+template <typename R> struct alignas(4 * sizeof(R)) Cube {  // hittable.rs:42-47
+  R p0[3], pad0;
+  R p1[3], pad1;
+};
+struct Attr {  // cold per-primitive attributes
+  uint32_t material, object;
+};
+struct Complex {
+  uint32_t body, op_first, op_count, medium_pos;  // medium_pos = index of the MEDIUM op in the chain, or REF_NONE
+  uint32_t material, object, pad0, pad1;
+};
+template <typename R> struct alignas(4 * sizeof(R)) Op {
+  R d[4];  // offset xyz | quaternion wxyz | neg_inv_density
+};
+template <typename R> struct Material {
+  uint32_t tag, texture;
+  R p[4];
+};
+template <typename R> struct Texture {
+  uint32_t tag, odd, even, width, height, pad;
+  uint64_t texel_offset;
+  R color[3];
+};
+template <typename R> struct Light {
+  uint32_t tag, pad;
+  R c[3], radius;
+};
+
+template <typename R> struct SceneView {
+  const Node<R>* nodes;
+  const Real4<R>* spheres;
+  const MSphere<R>* mspheres;
+  const Cube<R>* cubes;
+  const Attr* sphere_attr;
+  const Attr* msphere_attr;
+  const Attr* cube_attr;
+  const Complex* complexes;
+  const uint32_t* op_tag;
+  const Op<R>* ops;
+  const Material<R>* materials;
+  const Texture<R>* textures;
+  const uint8_t* texels;
+  const Light<R>* lights;
+  uint32_t root;
+  uint32_t lights_kind, n_lights;
+  R background[3];
+};
+
+template <typename R> struct CameraView {  // cam.rs:6-18
+  Vec3<R> origin, lower_left, horizontal, vertical, u, v;
+  Vec3<R> ll_rel;  // lower_left - origin, formed in f64 on the host (used by the f32 kernels only)
+  R lens_radius, time_open, time_close;
+};
+
+struct DeviceStats {  // one uint64 per rt_stats counter, in rt_stats order
+  unsigned long long v[17];
+};
+enum StatIdx {
+  ST_RAYS = 0, ST_LIGHT_PROBES, ST_MEDIUM_PROBES, ST_NODES, ST_SPHERE_TESTS, ST_SPHERE_HITS,
+  ST_CUBE_TESTS, ST_CUBE_HITS, ST_ROTATE, ST_TRANSLATE, ST_MEDIUM, ST_CLOSEST, ST_DIFFUSE,
+  ST_SPECULAR, ST_EMITTER, ST_MISSES, ST_NONFINITE, ST_COUNT
+};
+
+}  // namespace rt

@@ -1,0 +1,129 @@
+// C ABI of librt_host.so (include/rt_host.h).
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/rt_host.h"
+#include "rth.hpp"
+
+using namespace rth;
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+}  // namespace
+
+struct rth_scene {
+  FlatScene flat;
+  rt_scene_desc desc;
+  rt_camera camera;
+  uint32_t n_objects;
+};
+
+extern "C" {
+
+const char* rth_last_error(void) { return g_err.c_str(); }
+
+uint32_t rth_image_height(uint32_t image_width, double aspect_ratio) {
+  double h = (double)image_width / aspect_ratio;  // `as u32` truncates and saturates
+  if (!(h == h) || h <= 0.0) return 0;
+  if (h >= 4294967295.0) return 4294967295u;
+  return (uint32_t)h;
+}
+
+int rth_scene_build(const rth_scene_opts* o, rth_scene** out) {
+  if (!o || !out) return fail(RT_ERR_BAD_ARG, "rth_scene_build: null argument");
+  *out = nullptr;
+  try {
+    SceneOpts so;
+    so.scene_id = o->scene_id;
+    so.scene_seed = o->scene_seed;
+    so.n = o->n;
+    if (o->texels && o->tex_width && o->tex_height) {
+      so.texels = std::make_shared<const std::vector<uint8_t>>(o->texels,
+                                                               o->texels + (size_t)3 * o->tex_width * o->tex_height);
+      so.tex_w = o->tex_width;
+      so.tex_h = o->tex_height;
+    }
+    SceneDef def = scene_by_id(so);
+    RotateBBox mode = def.rotate_bbox;
+    if (o->rotate_bbox == 0) mode = RotateBBox::Reference;
+    if (o->rotate_bbox == 1) mode = RotateBBox::Correct;
+    auto* s = new rth_scene;
+    s->flat = flatten(def, o->bvh_seed, mode);
+    s->desc = s->flat.desc();
+    s->n_objects = s->flat.n_objects;
+    s->camera = camera_new(def.cam.lookfrom, def.cam.lookat, def.cam.vup, def.cam.vfov, o->aspect_ratio,
+                           def.cam.aperture, def.cam.focus_dist, def.cam.time_open, def.cam.time_close);
+    *out = s;
+    return RT_OK;
+  } catch (const std::exception& e) {
+    return fail(RT_ERR_BAD_ARG, std::string("rth_scene_build: ") + e.what());
+  }
+}
+
+void rth_scene_free(rth_scene* s) { delete s; }
+const rt_scene_desc* rth_scene_desc(const rth_scene* s) { return s ? &s->desc : nullptr; }
+const rt_camera* rth_scene_camera(const rth_scene* s) { return s ? &s->camera : nullptr; }
+uint32_t rth_scene_object_count(const rth_scene* s) { return s ? s->n_objects : 0; }
+uint32_t rth_scene_bvh_calls(const rth_scene* s) { return s ? s->flat.bvh.calls : 0; }
+
+int rth_camera_new(const double lookfrom[3], const double lookat[3], const double vup[3], double vfov,
+                   double aspect_ratio, double aperture, double focus_dist, double time_open, double time_close,
+                   rt_camera* out) {
+  if (!lookfrom || !lookat || !vup || !out) return fail(RT_ERR_BAD_ARG, "rth_camera_new: null argument");
+  *out = camera_new(Point(lookfrom[0], lookfrom[1], lookfrom[2]), Point(lookat[0], lookat[1], lookat[2]),
+                    Vector(vup[0], vup[1], vup[2]), vfov, aspect_ratio, aperture, focus_dist, time_open, time_close);
+  return RT_OK;
+}
+
+int rth_render(const rth_render_opts* o, uint8_t* rgb8, float* accum, uint32_t* height_out, rt_stats* stats) {
+  if (!o || !rgb8) return fail(RT_ERR_BAD_ARG, "rth_render: null argument");
+  const uint32_t w = o->image_width;
+  const uint32_t h = rth_image_height(w, o->scene.aspect_ratio);
+  if (height_out) *height_out = h;
+  rth_scene* hs = nullptr;
+  int rc = rth_scene_build(&o->scene, &hs);
+  if (rc != RT_OK) return rc;
+  rt_scene* ds = nullptr;
+  rc = rt_scene_create(o->device, &hs->desc, &ds);
+  if (rc != RT_OK) {
+    g_err = std::string("rth_render: ") + rt_last_error();
+    rth_scene_free(hs);
+    return rc;
+  }
+  rt_params p;
+  std::memset(&p, 0, sizeof(p));
+  p.width = w;
+  p.height = h;
+  p.spp = o->samples_per_pixel;
+  p.max_depth = o->max_depth;
+  p.seed = o->seed;
+  std::vector<float> local;
+  float* acc = accum;
+  if (!acc) {
+    local.resize((size_t)w * h * 3);
+    acc = local.data();
+  }
+  rc = rt_render(ds, &hs->camera, &p, acc, stats);
+  if (rc != RT_OK)
+    g_err = std::string("rth_render: ") + rt_last_error();
+  else
+    rt_tonemap(acc, (uint64_t)w * h, p.spp, rgb8);
+  rt_scene_destroy(ds);
+  rth_scene_free(hs);
+  return rc;
+}
+
+void rth_rotate(double angle_rad, const double axis[3], const double v[3], double out[3]) {
+  d3 r = rotate(d3(v[0], v[1], v[2]), new_quaternion(angle_rad, Vector(axis[0], axis[1], axis[2])));
+  out[0] = r[0];
+  out[1] = r[1];
+  out[2] = r[2];
+}
+int rth_bvh_axis(uint64_t bvh_seed, uint32_t call) { return bvh_axis(bvh_seed, call); }
+
+}  // extern "C"

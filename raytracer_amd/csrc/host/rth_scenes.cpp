@@ -1,0 +1,224 @@
+// Scene builders: the six scenes of scenes.rs:10-192 with the fixed camera / background of
+// main.rs:134-150, and the three benchmark scenes BASELINE.json names that the reference
+// lacks (Cornell box, BVH stress, final-scene composition), assembled only from reference
+// primitives.
+#include <stdexcept>
+
+#include "rth.hpp"
+
+namespace rth {
+
+static SceneDef with_reference_view() {
+  SceneDef s;
+  s.cam = CameraSpec{Point(13.0, 2.0, 3.0), Point(0.0, 0.0, 0.0), Vector(0.0, 1.0, 0.0), 20.0, 0.1, 10.0, 0.0, 1.0};
+  s.background = Color(0.50, 0.70, 1.00);
+  return s;
+}
+
+static Vector random_vector(Stream& r) {  // alias.rs:40-42
+  double x = r.next_f64(), y = r.next_f64(), z = r.next_f64();
+  return Vector(x, y, z);
+}
+static Color mul(Color a, Color b) { return Color(a[0] * b[0], a[1] * b[1], a[2] * b[2]); }
+
+SceneDef two_spheres() {
+  SceneDef s = with_reference_view();
+  Texture checker = Texture::new_checker_color(Color(0.2, 0.3, 0.1), Color(0.9, 0.9, 0.9));
+  s.world.push_back(Hittable::new_sphere(Point(0.0, -10.0, 0.0), 10.0, Material::new_lambertian_with_texture(checker)));
+  s.world.push_back(Hittable::new_sphere(Point(0.0, 10.0, 0.0), 10.0, Material::new_lambertian_with_texture(checker)));
+  return s;
+}
+
+SceneDef small_scene() {
+  SceneDef s = with_reference_view();
+  Material glass = Material::new_dielectric(1.5);
+  s.world.push_back(Hittable::new_sphere(Point(0.0, -100.5, -1.0), 100.0, Material::new_lambertian(Color(0.8, 0.8, 0.0))));
+  s.world.push_back(Hittable::new_sphere(Point(0.0, 0.0, -1.0), 0.5, Material::new_lambertian(Color(0.1, 0.2, 0.5))));
+  s.world.push_back(Hittable::new_sphere(Point(-1.0, 0.0, -1.0), 0.5, glass));
+  s.world.push_back(Hittable::new_sphere(Point(-1.0, 0.0, -1.0), -0.4, glass));  // hollow glass, Q15
+  s.world.push_back(Hittable::new_sphere(Point(1.0, 0.0, -1.0), 0.5, Material::new_metal(Color(0.8, 0.6, 0.2), 1.0)));
+  return s;
+}
+
+// Draw stream 0 replaces the seeded StdRng (scenes.rs:64), stream 1 the unseeded thread_rng
+// behind Vector::random_vector() (scenes.rs:77, Q18).
+SceneDef random_scene(uint64_t seed) {
+  SceneDef s = with_reference_view();
+  s.world.push_back(Hittable::new_sphere(
+      Point(0.0, -1000.0, 0.0), 1000.0,
+      Material::new_lambertian_with_texture(Texture::new_checker_color(Color(0.2, 0.3, 0.1), Color(0.9, 0.9, 0.9)))));
+  Stream main = scene_stream(seed, 0), albedo = scene_stream(seed, 1);
+  for (int a = -11; a < 11; ++a)
+    for (int b = -11; b < 11; ++b) {
+      const double choose_mat = main.next_f64();
+      const double x = (double)a + 0.9 * main.next_f64();
+      const double z = (double)b + 0.9 * main.next_f64();
+      const Point center(x, 0.2, z);
+      if (!(length(sub(center, Point(4.0, 0.2, 0.0))) > 0.9)) continue;
+      if (choose_mat < 0.8) {  // diffuse, moving
+        Vector v1 = random_vector(albedo), v2 = random_vector(albedo);
+        Material m = Material::new_lambertian(mul(v1, v2));
+        Point center2 = add(center, Vector(0.0, main.range(0.0, 0.5), 0.0));
+        s.world.push_back(Hittable::new_moving_sphere(center, center2, 0.0, 1.0, 0.2, m));
+      } else if (choose_mat < 0.95) {  // metal
+        double r = main.range(0.5, 1.0), g = main.range(0.5, 1.0), bl = main.range(0.5, 1.0);
+        double fuzz = main.range(0.0, 0.5);
+        s.world.push_back(Hittable::new_sphere(center, 0.2, Material::new_metal(Color(r, g, bl), fuzz)));
+      } else {  // glass
+        s.world.push_back(Hittable::new_sphere(center, 0.2, Material::new_dielectric(1.5)));
+      }
+    }
+  s.world.push_back(Hittable::new_sphere(Point(0.0, 1.0, 0.0), 1.0, Material::new_dielectric(1.5)));
+  s.world.push_back(Hittable::new_sphere(Point(-4.0, 1.0, 0.0), 1.0, Material::new_lambertian(Color(0.4, 0.2, 0.1))));
+  s.world.push_back(Hittable::new_sphere(Point(4.0, 1.0, 0.0), 1.0, Material::new_metal(Color(0.7, 0.6, 0.5), 0.0)));
+  return s;
+}
+
+static Texture earthmap(const SceneOpts& o) { return Texture::new_image_rgb8(o.texels, o.tex_w, o.tex_h); }
+
+SceneDef earth(const SceneOpts& o) {
+  SceneDef s = with_reference_view();
+  s.world.push_back(Hittable::new_sphere(Point(), 2.0, Material::new_lambertian_with_texture(earthmap(o))));
+  return s;
+}
+
+SceneDef simple_light() {
+  SceneDef s = with_reference_view();
+  s.lights.push_back(Hittable::new_sphere(Point(0.0, 2.0, 3.0), 1.0, Material::new_diffuse_light(Color(4.0, 4.0, 4.0))));
+  s.lights.push_back(Hittable::new_sphere(Point(2.0, 0.3, 1.0), 0.2, Material::new_dielectric(1.5)));  // Q7
+  s.world.push_back(Hittable::new_sphere(Point(0.0, -1000.0, 0.0), 1000.0, Material::new_lambertian(Color(0.8, 0.8, 0.0))));
+  s.world.push_back(Hittable::new_constant_medium(
+      Hittable::new_sphere(Point(0.0, 2.0, 0.0), 2.0, Material::new_lambertian(Color(0.8, 0.0, 0.0))), 0.91,
+      Color(0.0, 0.0, 0.0)));
+  s.world.push_back(Hittable::new_rotate(Hittable::new_cube(Point(0.0, 1.0, -1.7), Point(4.0, 2.0, -1.6),
+                                                            Material::new_lambertian_with_texture(Texture::new_normal())),
+                                         to_radians(5.0), Vector(0.0, 0.0, 1.0)));
+  s.world.insert(s.world.end(), s.lights.begin(), s.lights.end());  // lights are part of the world too
+  return s;
+}
+
+SceneDef cube_scene(const SceneOpts& o) {
+  SceneDef s = with_reference_view();
+  s.world.push_back(Hittable::new_rotate(
+      Hittable::new_cube(Point(-1.0, -1.0, -1.0), Point(1.0, 1.0, 1.0), Material::new_lambertian_with_texture(earthmap(o))),
+      -to_radians(45.0), Vector(0.0, 0.0, 1.0)));
+  return s;
+}
+
+SceneDef cornell_box() {
+  SceneDef s;
+  const Material red = Material::new_lambertian(Color(0.65, 0.05, 0.05));
+  const Material white = Material::new_lambertian(Color(0.73, 0.73, 0.73));
+  const Material green = Material::new_lambertian(Color(0.12, 0.45, 0.15));
+  const Material lamp = Material::new_diffuse_light(Color(15.0, 15.0, 15.0));
+  // walls: Cubes one unit thick, outside the 0..555 cavity
+  s.world.push_back(Hittable::new_cube(Point(555.0, 0.0, 0.0), Point(556.0, 555.0, 555.0), green));
+  s.world.push_back(Hittable::new_cube(Point(-1.0, 0.0, 0.0), Point(0.0, 555.0, 555.0), red));
+  s.world.push_back(Hittable::new_cube(Point(0.0, -1.0, 0.0), Point(555.0, 0.0, 555.0), white));
+  s.world.push_back(Hittable::new_cube(Point(0.0, 555.0, 0.0), Point(555.0, 556.0, 555.0), white));
+  s.world.push_back(Hittable::new_cube(Point(0.0, 0.0, 555.0), Point(555.0, 555.0, 556.0), white));
+  // the only light shape the reference can importance-sample is a Sphere (Q8)
+  const Hittable bulb = Hittable::new_sphere(Point(278.0, 480.0, 278.0), 60.0, lamp);
+  s.world.push_back(bulb);
+  // Rotate shows an object turned by MINUS its angle (Q4): +15 / -18 degrees are passed negated
+  s.world.push_back(Hittable::new_translate(
+      Hittable::new_rotate(Hittable::new_cube(Point(0.0, 0.0, 0.0), Point(165.0, 330.0, 165.0), white), to_radians(-15.0),
+                           Vector(0.0, 1.0, 0.0)),
+      Vector(265.0, 0.0, 295.0)));
+  s.world.push_back(Hittable::new_translate(
+      Hittable::new_rotate(Hittable::new_cube(Point(0.0, 0.0, 0.0), Point(165.0, 165.0, 165.0), white), to_radians(18.0),
+                           Vector(0.0, 1.0, 0.0)),
+      Vector(130.0, 0.0, 65.0)));
+  s.lights.push_back(bulb);
+  s.cam = CameraSpec{Point(278.0, 278.0, -800.0), Point(278.0, 278.0, 0.0), Vector(0.0, 1.0, 0.0), 40.0, 0.0, 10.0, 0.0, 1.0};
+  s.background = Color(0.0, 0.0, 0.0);
+  s.rotate_bbox = RotateBBox::Correct;
+  return s;
+}
+
+SceneDef bvh_stress(uint64_t seed, uint32_t n) {
+  SceneDef s = with_reference_view();
+  s.world.reserve((size_t)n + 1);
+  s.world.push_back(Hittable::new_sphere(
+      Point(0.0, -1000.0, 0.0), 1000.0,
+      Material::new_lambertian_with_texture(Texture::new_checker_color(Color(0.2, 0.3, 0.1), Color(0.9, 0.9, 0.9)))));
+  Stream r = scene_stream(seed, 0);
+  for (uint32_t i = 0; i < n; ++i) {
+    const double choose_mat = r.next_f64();
+    const double x = r.range(-40.0, 40.0);
+    const double y = r.range(0.1, 20.0);
+    const double z = r.range(-40.0, 40.0);
+    const double radius = r.range(0.05, 0.15);
+    Material m;
+    if (choose_mat < 0.8) {
+      Vector v1 = random_vector(r), v2 = random_vector(r);
+      m = Material::new_lambertian(mul(v1, v2));
+    } else if (choose_mat < 0.95) {
+      double cr = r.range(0.5, 1.0), cg = r.range(0.5, 1.0), cb = r.range(0.5, 1.0);
+      double fuzz = r.range(0.0, 0.5);
+      m = Material::new_metal(Color(cr, cg, cb), fuzz);
+    } else {
+      m = Material::new_dielectric(1.5);
+    }
+    s.world.push_back(Hittable::new_sphere(Point(x, y, z), radius, m));
+  }
+  return s;
+}
+
+SceneDef final_scene(const SceneOpts& o) {
+  SceneDef s;
+  Stream r = scene_stream(o.scene_seed, 0);
+  const Material ground = Material::new_lambertian(Color(0.48, 0.83, 0.53));
+  for (int i = 0; i < 20; ++i)
+    for (int j = 0; j < 20; ++j) {
+      const double w = 100.0;
+      const double x0 = -1000.0 + i * w, z0 = -1000.0 + j * w;
+      const double y1 = r.range(1.0, 101.0);
+      s.world.push_back(Hittable::new_cube(Point(x0, 0.0, z0), Point(x0 + w, y1, z0 + w), ground));
+    }
+  const Hittable lamp =
+      Hittable::new_sphere(Point(273.0, 654.0, 279.5), 100.0, Material::new_diffuse_light(Color(7.0, 7.0, 7.0)));
+  s.world.push_back(lamp);
+  s.lights.push_back(lamp);
+  const Point c1(400.0, 400.0, 200.0);
+  s.world.push_back(Hittable::new_moving_sphere(c1, add(c1, Vector(30.0, 0.0, 0.0)), 0.0, 1.0, 50.0,
+                                                Material::new_lambertian(Color(0.7, 0.3, 0.1))));
+  s.world.push_back(Hittable::new_sphere(Point(260.0, 150.0, 45.0), 50.0, Material::new_dielectric(1.5)));
+  s.world.push_back(Hittable::new_sphere(Point(0.0, 150.0, 145.0), 50.0, Material::new_metal(Color(0.8, 0.8, 0.9), 1.0)));
+  const Hittable glass_ball = Hittable::new_sphere(Point(360.0, 150.0, 145.0), 70.0, Material::new_dielectric(1.5));
+  s.world.push_back(glass_ball);
+  s.world.push_back(Hittable::new_constant_medium(glass_ball, 0.2, Color(0.2, 0.4, 0.9)));
+  s.world.push_back(Hittable::new_constant_medium(
+      Hittable::new_sphere(Point(0.0, 0.0, 0.0), 5000.0, Material::new_dielectric(1.5)), 0.0001, Color(1.0, 1.0, 1.0)));
+  s.world.push_back(Hittable::new_sphere(Point(400.0, 200.0, 400.0), 100.0, Material::new_lambertian_with_texture(earthmap(o))));
+  s.world.push_back(Hittable::new_sphere(
+      Point(220.0, 280.0, 300.0), 80.0,
+      Material::new_lambertian_with_texture(Texture::new_checker_color(Color(0.2, 0.3, 0.1), Color(0.9, 0.9, 0.9)))));
+  const Material white = Material::new_lambertian(Color(0.73, 0.73, 0.73));
+  for (int j = 0; j < 1000; ++j) {
+    const double x = r.range(0.0, 165.0), y = r.range(0.0, 165.0), z = r.range(0.0, 165.0);
+    s.world.push_back(Hittable::new_translate(
+        Hittable::new_rotate(Hittable::new_sphere(Point(x, y, z), 10.0, white), to_radians(-15.0), Vector(0.0, 1.0, 0.0)),
+        Vector(-100.0, 270.0, 395.0)));
+  }
+  s.cam = CameraSpec{Point(478.0, 278.0, -600.0), Point(278.0, 278.0, 0.0), Vector(0.0, 1.0, 0.0), 40.0, 0.0, 10.0, 0.0, 1.0};
+  s.background = Color(0.0, 0.0, 0.0);
+  s.rotate_bbox = RotateBBox::Correct;
+  return s;
+}
+
+SceneDef scene_by_id(const SceneOpts& o) {
+  switch (o.scene_id) {
+    case 0: return random_scene(o.scene_seed);
+    case 1: return two_spheres();
+    case 2: return earth(o);
+    case 3: return simple_light();
+    case 4: return cube_scene(o);
+    case 6: return cornell_box();
+    case 7: return bvh_stress(o.scene_seed, o.n);
+    case 8: return final_scene(o);
+    default: return small_scene();  // main.rs:123
+  }
+}
+
+}  // namespace rth

@@ -1,0 +1,38 @@
+// Host-visible launchers of the gfx950 kernels, one set per device precision.  rt_f32.hip
+// (production, contraction on) and rt_f64.hip (audit, -ffp-contract=off) each instantiate
+// the templates in device/kernels.hpp; rt_api.hip calls them through these declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device/scene_view.hpp"
+
+namespace rt {
+
+struct RenderArgs;
+
+struct LaunchShape {
+  uint32_t tiles;        // 16x16 pixel tiles = workgroups along grid.x
+  uint32_t splits;       // sample splits along grid.y (atomic accumulation when > 1)
+  uint32_t stack_depth;  // LDS traversal-stack entries per lane
+};
+
+#define RT_DECLARE_LAUNCHERS(SUFFIX, REAL)                                                                  \
+  hipError_t launch_render_##SUFFIX(const SceneView<REAL>& sc, const CameraView<REAL>& cam, uint32_t width, \
+                                    uint32_t height, uint32_t sample_begin, uint32_t n_samples,             \
+                                    uint32_t max_depth, uint64_t seed, int accumulate, bool stats,          \
+                                    REAL* accum, DeviceStats* dstats, LaunchShape shape, hipStream_t st);   \
+  hipError_t launch_primary_##SUFFIX(const SceneView<REAL>& sc, const CameraView<REAL>& cam, uint32_t width, \
+                                     uint32_t height, uint64_t seed, REAL time, uint32_t* prim_id, REAL* t, \
+                                     REAL* normal, REAL* uv, uint8_t* front_face, LaunchShape shape,        \
+                                     hipStream_t st);                                                       \
+  hipError_t launch_kat_sphere_uv_##SUFFIX(uint32_t n, const double* p, double* uv, hipStream_t st);        \
+  hipError_t launch_kat_rotate_##SUFFIX(uint32_t n, const double* angle, const double* axis,                \
+                                        const double* v, double* out, hipStream_t st);
+
+RT_DECLARE_LAUNCHERS(f32, float)
+RT_DECLARE_LAUNCHERS(f64, double)
+
+hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t* out, hipStream_t st);
+hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t* out, hipStream_t st);
+
+}  // namespace rt

@@ -1,0 +1,68 @@
+// Included by rt_f32.hip and rt_f64.hip with RT_SUFFIX / RT_REAL / RT_EARLY_EXIT defined.
+#include "device/kernels.hpp"
+#include "launch.hpp"
+
+namespace rt {
+
+#define RT_CAT_(a, b) a##b
+#define RT_CAT(a, b) RT_CAT_(a, b)
+
+hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const CameraView<RT_REAL>& cam,
+                                             uint32_t width, uint32_t height, uint32_t sample_begin,
+                                             uint32_t n_samples, uint32_t max_depth, uint64_t seed, int accumulate,
+                                             bool stats, RT_REAL* accum, DeviceStats* dstats, LaunchShape shape,
+                                             hipStream_t st) {
+  RenderArgs a;
+  a.width = width;
+  a.height = height;
+  a.sample_begin = sample_begin;
+  a.n_samples = n_samples;
+  a.max_depth = max_depth;
+  a.accumulate = accumulate ? 1u : 0u;
+  a.splits = shape.splits;
+  a.seed = seed;
+  dim3 grid(shape.tiles, shape.splits, 1), block(BLOCK, 1, 1);
+  size_t lds = (size_t)shape.stack_depth * BLOCK * sizeof(uint32_t);
+  if (stats)
+    hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT>), grid, block, lds, st, sc, cam, a, accum, dstats);
+  else
+    hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT>), grid, block, lds, st, sc, cam, a, accum, dstats);
+  return hipGetLastError();
+}
+
+hipError_t RT_CAT(launch_primary_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const CameraView<RT_REAL>& cam,
+                                              uint32_t width, uint32_t height, uint64_t seed, RT_REAL time,
+                                              uint32_t* prim_id, RT_REAL* t, RT_REAL* normal, RT_REAL* uv,
+                                              uint8_t* front_face, LaunchShape shape, hipStream_t st) {
+  dim3 grid(shape.tiles, 1, 1), block(BLOCK, 1, 1);
+  size_t lds = (size_t)shape.stack_depth * BLOCK * sizeof(uint32_t);
+  hipLaunchKernelGGL((primary_kernel<RT_REAL>), grid, block, lds, st, sc, cam, width, height, seed, time, prim_id, t,
+                     normal, uv, front_face);
+  return hipGetLastError();
+}
+
+hipError_t RT_CAT(launch_kat_sphere_uv_, RT_SUFFIX)(uint32_t n, const double* p, double* uv, hipStream_t st) {
+  hipLaunchKernelGGL((kat_sphere_uv_kernel<RT_REAL>), dim3((n + 63) / 64), dim3(64), 0, st, n, p, uv);
+  return hipGetLastError();
+}
+hipError_t RT_CAT(launch_kat_rotate_, RT_SUFFIX)(uint32_t n, const double* angle, const double* axis,
+                                                 const double* v, double* out, hipStream_t st) {
+  hipLaunchKernelGGL((kat_rotate_kernel<RT_REAL>), dim3((n + 63) / 64), dim3(64), 0, st, n, angle, axis, v, out);
+  return hipGetLastError();
+}
+
+#ifdef RT_DEFINE_COMMON
+hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t* out, hipStream_t st) {
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(tonemap_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, accum, n, inv_spp, out);
+  return hipGetLastError();
+}
+hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(kat_philox_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, ctr, key, out);
+  return hipGetLastError();
+}
+#endif
+
+}  // namespace rt

@@ -1,0 +1,659 @@
+// C ABI of librt_hip.so (include/rt.h): scene validation and upload, launch orchestration,
+// error reporting.  Host code only; the kernels live in device/*.hpp and are instantiated
+// by rt_f32.hip / rt_f64.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt.h"
+#include "launch.hpp"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// f64 -> device precision.  Box bounds round OUTWARD in f32 so that a ray that passes the
+// reference's f64 slab test also passes the f32 one (conservative traversal).
+template <typename R> R conv(double v) { return (R)v; }
+float conv_down(double v) {
+  float f = (float)v;
+  return (double)f > v ? std::nextafterf(f, -INFINITY) : f;
+}
+float conv_up(double v) {
+  float f = (float)v;
+  return (double)f < v ? std::nextafterf(f, INFINITY) : f;
+}
+template <typename R> R conv_lo(double v);
+template <typename R> R conv_hi(double v);
+template <> double conv_lo<double>(double v) { return v; }
+template <> double conv_hi<double>(double v) { return v; }
+template <> float conv_lo<float>(double v) { return conv_down(v); }
+template <> float conv_hi<float>(double v) { return conv_up(v); }
+
+struct DeviceBuffers {
+  std::vector<void*> ptrs;
+  ~DeviceBuffers() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <typename T> hipError_t upload(const std::vector<T>& host, const T** out) {
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(host.size(), 1) * sizeof(T);  // never a null array
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e != hipSuccess) return e;
+    ptrs.push_back(d);
+    if (!host.empty()) {
+      e = hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
+      if (e != hipSuccess) return e;
+    } else {
+      e = hipMemset(d, 0, bytes);
+      if (e != hipSuccess) return e;
+    }
+    *out = (const T*)d;
+    return hipSuccess;
+  }
+};
+
+template <typename R> struct SceneSide {
+  DeviceBuffers bufs;
+  SceneView<R> view{};
+};
+
+template <typename R> hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& complexes, SceneSide<R>& s) {
+  std::vector<Node<R>> nodes(d.n_nodes);
+  for (uint32_t i = 0; i < d.n_nodes; ++i) {
+    std::memset(&nodes[i], 0, sizeof(Node<R>));
+    for (int k = 0; k < 3; ++k) {
+      nodes[i].lo[k] = conv_lo<R>(d.node_box[6 * (size_t)i + k]);
+      nodes[i].hi[k] = conv_hi<R>(d.node_box[6 * (size_t)i + 3 + k]);
+    }
+    nodes[i].left = d.node_left[i];
+    nodes[i].right = d.node_right[i];
+  }
+  std::vector<Real4<R>> spheres(d.n_spheres);
+  std::vector<Attr> sphere_attr(d.n_spheres);
+  for (uint32_t i = 0; i < d.n_spheres; ++i) {
+    const double* p = d.sphere + 4 * (size_t)i;
+    spheres[i] = Real4<R>{conv<R>(p[0]), conv<R>(p[1]), conv<R>(p[2]), conv<R>(p[3])};
+    sphere_attr[i] = Attr{d.sphere_material[i], d.sphere_object[i]};
+  }
+  std::vector<MSphere<R>> mspheres(d.n_mspheres);
+  std::vector<Attr> msphere_attr(d.n_mspheres);
+  for (uint32_t i = 0; i < d.n_mspheres; ++i) {
+    const double* p = d.msphere + 9 * (size_t)i;
+    MSphere<R> m;
+    std::memset(&m, 0, sizeof(m));
+    for (int k = 0; k < 3; ++k) {
+      m.c0[k] = conv<R>(p[k]);
+      m.c1[k] = conv<R>(p[3 + k]);
+    }
+    m.radius = conv<R>(p[6]);
+    m.t0 = conv<R>(p[7]);
+    m.t1 = conv<R>(p[8]);
+    mspheres[i] = m;
+    msphere_attr[i] = Attr{d.msphere_material[i], d.msphere_object[i]};
+  }
+  std::vector<Cube<R>> cubes(d.n_cubes);
+  std::vector<Attr> cube_attr(d.n_cubes);
+  for (uint32_t i = 0; i < d.n_cubes; ++i) {
+    const double* p = d.cube + 6 * (size_t)i;
+    Cube<R> c;
+    std::memset(&c, 0, sizeof(c));
+    for (int k = 0; k < 3; ++k) {
+      c.p0[k] = conv<R>(p[k]);
+      c.p1[k] = conv<R>(p[3 + k]);
+    }
+    cubes[i] = c;
+    cube_attr[i] = Attr{d.cube_material[i], d.cube_object[i]};
+  }
+  std::vector<uint32_t> op_tag(d.n_ops);
+  std::vector<Op<R>> ops(d.n_ops);
+  for (uint32_t i = 0; i < d.n_ops; ++i) {
+    op_tag[i] = d.op_tag[i];
+    for (int k = 0; k < 4; ++k) ops[i].d[k] = conv<R>(d.op_data[4 * (size_t)i + k]);
+  }
+  std::vector<Material<R>> mats(d.n_materials);
+  for (uint32_t i = 0; i < d.n_materials; ++i) {
+    mats[i].tag = d.mat_tag[i];
+    mats[i].texture = d.mat_texture[i];
+    for (int k = 0; k < 4; ++k) mats[i].p[k] = conv<R>(d.mat_params[4 * (size_t)i + k]);
+  }
+  std::vector<Texture<R>> texs(d.n_textures);
+  for (uint32_t i = 0; i < d.n_textures; ++i) {
+    std::memset(&texs[i], 0, sizeof(Texture<R>));
+    texs[i].tag = d.tex_tag[i];
+    texs[i].odd = d.tex_odd[i];
+    texs[i].even = d.tex_even[i];
+    texs[i].width = d.tex_width[i];
+    texs[i].height = d.tex_height[i];
+    texs[i].texel_offset = d.tex_texel_offset[i];
+    for (int k = 0; k < 3; ++k) texs[i].color[k] = conv<R>(d.tex_color[3 * (size_t)i + k]);
+  }
+  std::vector<uint8_t> texels(d.texels, d.texels + (d.texels ? d.n_texel_bytes : 0));
+  std::vector<Light<R>> lights(d.n_lights);
+  for (uint32_t i = 0; i < d.n_lights; ++i) {
+    std::memset(&lights[i], 0, sizeof(Light<R>));
+    lights[i].tag = d.light_tag[i];
+    for (int k = 0; k < 3; ++k) lights[i].c[k] = conv<R>(d.light_sphere[4 * (size_t)i + k]);
+    lights[i].radius = conv<R>(d.light_sphere[4 * (size_t)i + 3]);
+  }
+  hipError_t e;
+#define UP(vec, field) \
+  if ((e = s.bufs.upload(vec, &s.view.field)) != hipSuccess) return e;
+  UP(nodes, nodes)
+  UP(spheres, spheres)
+  UP(mspheres, mspheres)
+  UP(cubes, cubes)
+  UP(sphere_attr, sphere_attr)
+  UP(msphere_attr, msphere_attr)
+  UP(cube_attr, cube_attr)
+  UP(complexes, complexes)
+  UP(op_tag, op_tag)
+  UP(ops, ops)
+  UP(mats, materials)
+  UP(texs, textures)
+  UP(texels, texels)
+  UP(lights, lights)
+#undef UP
+  s.view.root = d.root;
+  s.view.lights_kind = d.lights_kind;
+  s.view.n_lights = d.n_lights;
+  for (int k = 0; k < 3; ++k) s.view.background[k] = conv<R>(d.background[k]);
+  return hipSuccess;
+}
+
+template <typename R> CameraView<R> to_camera(const rt_camera& c) {
+  auto v3 = [](const double* p) { return Vec3<R>((R)p[0], (R)p[1], (R)p[2]); };
+  CameraView<R> o;
+  o.origin = v3(c.origin);
+  o.lower_left = v3(c.lower_left);
+  o.horizontal = v3(c.horizontal);
+  o.vertical = v3(c.vertical);
+  o.u = v3(c.u);
+  o.v = v3(c.v);
+  o.ll_rel = Vec3<R>((R)(c.lower_left[0] - c.origin[0]), (R)(c.lower_left[1] - c.origin[1]),
+                     (R)(c.lower_left[2] - c.origin[2]));
+  o.lens_radius = (R)c.lens_radius;
+  o.time_open = (R)c.time_open;
+  o.time_close = (R)c.time_close;
+  return o;
+}
+
+bool is_simple_leaf(uint32_t ref, const rt_scene_desc& d) {
+  if (ref == RT_REF_NONE || !(ref & RT_REF_LEAF)) return false;
+  uint32_t k = RT_REF_KIND(ref), i = RT_REF_INDEX(ref);
+  if (k == RT_LEAF_SPHERE) return i < d.n_spheres;
+  if (k == RT_LEAF_MSPHERE) return i < d.n_mspheres;
+  if (k == RT_LEAF_CUBE) return i < d.n_cubes;
+  return false;
+}
+bool is_valid_leaf(uint32_t ref, const rt_scene_desc& d) {
+  if (is_simple_leaf(ref, d)) return true;
+  if (ref == RT_REF_NONE || !(ref & RT_REF_LEAF)) return false;
+  return RT_REF_KIND(ref) == RT_LEAF_COMPLEX && RT_REF_INDEX(ref) < d.n_complex;
+}
+
+constexpr uint32_t MAX_STACK_DEPTH = 64;
+constexpr uint32_t TARGET_WAVES = 256u * 16u;  // enough waves to fill 256 CUs at 4 waves/SIMD
+
+}  // namespace
+
+struct rt_scene {
+  int device = 0;
+  uint32_t stack_depth = 1;
+  SceneSide<float> f32;
+  SceneSide<double> f64;
+  DeviceStats* dstats = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  ~rt_scene() {
+    if (dstats) (void)hipFree(dstats);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+  }
+};
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
+  if (!d || !out) return fail(RT_ERR_BAD_ARG, "rt_scene_create: null argument");
+  *out = nullptr;
+  if (d->abi_version != RT_ABI_VERSION)
+    return fail(RT_ERR_BAD_ARG, "rt_scene_create: abi_version %u, library is %u", d->abi_version, RT_ABI_VERSION);
+#define NEED(cond, what) \
+  if (!(cond)) return fail(RT_ERR_BAD_ARG, "rt_scene_create: %s", what);
+  NEED(d->n_nodes == 0 || (d->node_box && d->node_left && d->node_right), "null node arrays");
+  NEED(d->n_spheres == 0 || (d->sphere && d->sphere_material && d->sphere_object), "null sphere arrays");
+  NEED(d->n_mspheres == 0 || (d->msphere && d->msphere_material && d->msphere_object), "null moving-sphere arrays");
+  NEED(d->n_cubes == 0 || (d->cube && d->cube_material && d->cube_object), "null cube arrays");
+  NEED(d->n_complex == 0 || (d->complex_body && d->complex_op_first && d->complex_op_count && d->complex_material &&
+                             d->complex_object),
+       "null complex arrays");
+  NEED(d->n_ops == 0 || (d->op_tag && d->op_data), "null op arrays");
+  NEED(d->n_materials == 0 || (d->mat_tag && d->mat_texture && d->mat_params), "null material arrays");
+  NEED(d->n_textures == 0 || (d->tex_tag && d->tex_color && d->tex_odd && d->tex_even && d->tex_texel_offset &&
+                              d->tex_width && d->tex_height),
+       "null texture arrays");
+  NEED(d->n_texel_bytes == 0 || d->texels, "null texels");
+  NEED(d->n_lights == 0 || (d->light_tag && d->light_sphere), "null light arrays");
+  NEED(d->n_nodes < 0x80000000u && d->n_spheres <= 0x0FFFFFFFu && d->n_mspheres <= 0x0FFFFFFFu &&
+           d->n_cubes <= 0x0FFFFFFFu && d->n_complex <= 0x0FFFFFFFu,
+       "too many elements for a 28-bit leaf index");
+  NEED(d->lights_kind <= RT_LIGHTS_LIST, "bad lights_kind");
+  NEED((d->lights_kind == RT_LIGHTS_NONE) == (d->n_lights == 0), "lights_kind / n_lights mismatch");
+  NEED(d->lights_kind != RT_LIGHTS_SINGLE || d->n_lights == 1, "RT_LIGHTS_SINGLE needs exactly one light");
+  for (uint32_t i = 0; i < d->n_lights; ++i) NEED(d->light_tag[i] <= RT_LIGHT_OTHER, "bad light tag");
+
+  // textures: tags, checker children in range and acyclic (children must have a larger index)
+  for (uint32_t i = 0; i < d->n_textures; ++i) {
+    NEED(d->tex_tag[i] <= RT_TEX_UV, "bad texture tag");
+    if (d->tex_tag[i] == RT_TEX_CHECKER)
+      NEED(d->tex_odd[i] < d->n_textures && d->tex_even[i] < d->n_textures && d->tex_odd[i] > i && d->tex_even[i] > i,
+           "checker children must be textures with a larger index");
+    if (d->tex_tag[i] == RT_TEX_IMAGE) {
+      NEED(d->tex_width[i] > 0 && d->tex_height[i] > 0, "empty image texture");
+      NEED(d->tex_texel_offset[i] + 3ull * d->tex_width[i] * d->tex_height[i] <= d->n_texel_bytes,
+           "image texture outside texels");
+    }
+  }
+  for (uint32_t i = 0; i < d->n_materials; ++i) {
+    NEED(d->mat_tag[i] <= RT_MAT_ISOTROPIC, "bad material tag");
+    bool textured = d->mat_tag[i] == RT_MAT_LAMBERTIAN || d->mat_tag[i] == RT_MAT_DIFFUSE_LIGHT ||
+                    d->mat_tag[i] == RT_MAT_ISOTROPIC;
+    if (textured) NEED(d->mat_texture[i] < d->n_textures, "material texture out of range");
+  }
+  for (uint32_t i = 0; i < d->n_spheres; ++i) NEED(d->sphere_material[i] < d->n_materials, "sphere material out of range");
+  for (uint32_t i = 0; i < d->n_mspheres; ++i)
+    NEED(d->msphere_material[i] < d->n_materials, "moving-sphere material out of range");
+  for (uint32_t i = 0; i < d->n_cubes; ++i) NEED(d->cube_material[i] < d->n_materials, "cube material out of range");
+
+  std::vector<Complex> complexes(d->n_complex);
+  for (uint32_t i = 0; i < d->n_complex; ++i) {
+    if (!is_simple_leaf(d->complex_body[i], *d))
+      return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: complex %u body must be a sphere / moving sphere / cube leaf", i);
+    NEED((uint64_t)d->complex_op_first[i] + d->complex_op_count[i] <= d->n_ops, "complex op range out of bounds");
+    Complex c{};
+    c.body = d->complex_body[i];
+    c.op_first = d->complex_op_first[i];
+    c.op_count = d->complex_op_count[i];
+    c.medium_pos = REF_NONE;
+    c.material = d->complex_material[i];
+    c.object = d->complex_object[i];
+    for (uint32_t k = 0; k < c.op_count; ++k) {
+      uint8_t tag = d->op_tag[c.op_first + k];
+      NEED(tag <= RT_OP_MEDIUM, "bad op tag");
+      if (tag == RT_OP_MEDIUM) {
+        if (c.medium_pos != REF_NONE)
+          return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: complex %u nests two constant media", i);
+        c.medium_pos = k;
+      }
+    }
+    if (c.medium_pos != REF_NONE) NEED(c.material < d->n_materials, "medium material out of range");
+    complexes[i] = c;
+  }
+
+  // BVH: pre-order (children after parents) makes it acyclic; compute its height bottom-up.
+  std::vector<uint32_t> height(d->n_nodes, 0);
+  for (uint32_t ii = d->n_nodes; ii-- > 0;) {
+    uint32_t h = 0;
+    for (uint32_t ref : {d->node_left[ii], d->node_right[ii]}) {
+      if (ref & RT_REF_LEAF) {
+        NEED(is_valid_leaf(ref, *d), "node child is not a valid leaf");
+      } else {
+        NEED(ref < d->n_nodes && ref > ii, "node child must be a later node (pre-order)");
+        h = std::max(h, height[ref]);
+      }
+    }
+    height[ii] = h + 1;
+  }
+  uint32_t tree_height = 0;
+  if (d->root == RT_REF_NONE) {
+  } else if (d->root & RT_REF_LEAF) {
+    NEED(is_valid_leaf(d->root, *d), "root is not a valid leaf");
+  } else {
+    NEED(d->root < d->n_nodes, "root out of range");
+    tree_height = height[d->root];
+  }
+#undef NEED
+  if (tree_height > MAX_STACK_DEPTH)
+    return fail(RT_ERR_STACK_DEPTH, "rt_scene_create: BVH height %u exceeds the %u-entry LDS stack", tree_height,
+                MAX_STACK_DEPTH);
+
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(RT_ERR_BAD_ARG, "rt_scene_create: device %d of %d", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  rt_scene* s = new rt_scene;
+  s->device = device;
+  s->stack_depth = std::max(tree_height, 1u);
+  hipError_t e;
+  if ((e = build_side<float>(*d, complexes, s->f32)) != hipSuccess ||
+      (e = build_side<double>(*d, complexes, s->f64)) != hipSuccess ||
+      (e = hipMalloc((void**)&s->dstats, sizeof(DeviceStats))) != hipSuccess ||
+      (e = hipEventCreate(&s->ev0)) != hipSuccess || (e = hipEventCreate(&s->ev1)) != hipSuccess) {
+    delete s;
+    return fail(RT_ERR_HIP, "rt_scene_create: upload failed: %s", hipGetErrorString(e));
+  }
+  *out = s;
+  return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  delete s;
+}
+
+}  // extern "C"
+
+namespace {
+
+int check_camera(const rt_camera* cam) {
+  if (!cam) return fail(RT_ERR_BAD_ARG, "null camera");
+  // gen_range(time_open..time_close) panics on an empty range (cam.rs:69)
+  if (!(cam->time_open < cam->time_close)) return fail(RT_ERR_BAD_ARG, "camera shutter interval is empty (cam.rs:69)");
+  return RT_OK;
+}
+
+LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_samples) {
+  LaunchShape sh;
+  uint32_t tx = (w + 15) / 16, ty = (h + 15) / 16;
+  sh.tiles = tx * ty;
+  sh.stack_depth = s->stack_depth;
+  uint32_t waves = sh.tiles * 4;
+  uint32_t splits = waves >= TARGET_WAVES ? 1 : (TARGET_WAVES + waves - 1) / waves;
+  sh.splits = std::max(1u, std::min(splits, n_samples));
+  return sh;
+}
+
+template <typename R> struct Side;
+template <> struct Side<float> {
+  static SceneSide<float>& get(rt_scene* s) { return s->f32; }
+  static hipError_t render(const SceneView<float>& sc, const CameraView<float>& cam, uint32_t w, uint32_t h, uint32_t sb,
+                           uint32_t ns, uint32_t md, uint64_t seed, int acc, bool st, float* a, DeviceStats* ds,
+                           LaunchShape sh, hipStream_t str) {
+    return launch_render_f32(sc, cam, w, h, sb, ns, md, seed, acc, st, a, ds, sh, str);
+  }
+  static hipError_t primary(const SceneView<float>& sc, const CameraView<float>& cam, uint32_t w, uint32_t h,
+                            uint64_t seed, float time, uint32_t* id, float* t, float* n, float* uv, uint8_t* ff,
+                            LaunchShape sh, hipStream_t str) {
+    return launch_primary_f32(sc, cam, w, h, seed, time, id, t, n, uv, ff, sh, str);
+  }
+};
+template <> struct Side<double> {
+  static SceneSide<double>& get(rt_scene* s) { return s->f64; }
+  static hipError_t render(const SceneView<double>& sc, const CameraView<double>& cam, uint32_t w, uint32_t h,
+                           uint32_t sb, uint32_t ns, uint32_t md, uint64_t seed, int acc, bool st, double* a,
+                           DeviceStats* ds, LaunchShape sh, hipStream_t str) {
+    return launch_render_f64(sc, cam, w, h, sb, ns, md, seed, acc, st, a, ds, sh, str);
+  }
+  static hipError_t primary(const SceneView<double>& sc, const CameraView<double>& cam, uint32_t w, uint32_t h,
+                            uint64_t seed, double time, uint32_t* id, double* t, double* n, double* uv, uint8_t* ff,
+                            LaunchShape sh, hipStream_t str) {
+    return launch_primary_f64(sc, cam, w, h, seed, time, id, t, n, uv, ff, sh, str);
+  }
+};
+
+void stats_to_abi(const DeviceStats& d, rt_stats* o) {
+  o->rays = d.v[ST_RAYS];
+  o->light_probes = d.v[ST_LIGHT_PROBES];
+  o->medium_probes = d.v[ST_MEDIUM_PROBES];
+  o->nodes_visited = d.v[ST_NODES];
+  o->sphere_tests = d.v[ST_SPHERE_TESTS];
+  o->sphere_hits = d.v[ST_SPHERE_HITS];
+  o->cube_tests = d.v[ST_CUBE_TESTS];
+  o->cube_hits = d.v[ST_CUBE_HITS];
+  o->rotate_visits = d.v[ST_ROTATE];
+  o->translate_visits = d.v[ST_TRANSLATE];
+  o->medium_visits = d.v[ST_MEDIUM];
+  o->closest_hits = d.v[ST_CLOSEST];
+  o->diffuse_vertices = d.v[ST_DIFFUSE];
+  o->specular_vertices = d.v[ST_SPECULAR];
+  o->emitter_hits = d.v[ST_EMITTER];
+  o->misses = d.v[ST_MISSES];
+  o->nonfinite_samples = d.v[ST_NONFINITE];
+}
+
+// Enqueue the launches of one render call on `stream`; accum is device memory.
+template <typename R>
+int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d_accum, int accumulate,
+                     hipStream_t stream, rt_stats* stats) {
+  if (!s || !p || !d_accum) return fail(RT_ERR_BAD_ARG, "rt_render: null argument");
+  if (int rc = check_camera(cam)) return rc;
+  if (p->width < 2 || p->height < 2)  // u = (x + ξ) / (w - 1), main.rs:161
+    return fail(RT_ERR_BAD_ARG, "rt_render: image must be at least 2x2 (main.rs:161-163 divides by w-1, h-1)");
+  if ((uint64_t)p->width * p->height > 0xFFFFFFFFull / 3) return fail(RT_ERR_BAD_ARG, "rt_render: image too large");
+  if (p->sample_offset + p->spp > 0xFFFFFFFFull) return fail(RT_ERR_BAD_ARG, "rt_render: sample index exceeds 32 bits");
+  HIP_TRY(hipSetDevice(s->device));
+  const bool want_stats = (p->flags & RT_FLAG_STATS) != 0;
+  CameraView<R> cv = to_camera<R>(*cam);
+  const SceneView<R>& sv = Side<R>::get(s).view;
+  uint32_t per_launch = p->spp_per_launch ? p->spp_per_launch : 64u;
+  HIP_TRY(hipMemsetAsync(s->dstats, 0, sizeof(DeviceStats), stream));
+  HIP_TRY(hipEventRecord(s->ev0, stream));
+  uint32_t done = 0, launches = 0;
+  bool first = true;
+  const size_t accum_bytes = (size_t)p->width * p->height * 3 * sizeof(R);
+  if (p->spp == 0 && !accumulate) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
+  while (done < p->spp) {
+    uint32_t n = std::min(per_launch, p->spp - done);
+    LaunchShape sh = make_shape(s, p->width, p->height, n);
+    int acc = (accumulate || !first) ? 1 : 0;
+    if (sh.splits > 1 && !acc) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
+    HIP_TRY(Side<R>::render(sv, cv, p->width, p->height, (uint32_t)(p->sample_offset + done), n, p->max_depth, p->seed,
+                            acc, want_stats, d_accum, s->dstats, sh, stream));
+    done += n;
+    first = false;
+    ++launches;
+  }
+  HIP_TRY(hipEventRecord(s->ev1, stream));
+  if (stats) {
+    DeviceStats hs;
+    HIP_TRY(hipMemcpyAsync(&hs, s->dstats, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::memset(stats, 0, sizeof(*stats));
+    stats_to_abi(hs, stats);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->kernel_ms = ms;
+    stats->launches = launches;
+  }
+  return RT_OK;
+}
+
+template <typename R>
+int render_to_host(rt_scene* s, const rt_camera* cam, const rt_params* p, R* h_accum, rt_stats* stats) {
+  if (!s || !p || !h_accum) return fail(RT_ERR_BAD_ARG, "rt_render: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  size_t bytes = (size_t)p->width * p->height * 3 * sizeof(R);
+  R* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, std::max<size_t>(bytes, 16)));
+  rt_stats local;
+  int rc = render_on_device<R>(s, cam, p, d, 0, nullptr, stats ? stats : &local);
+  if (rc == RT_OK) {
+    hipError_t e = hipMemcpy(h_accum, d, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(RT_ERR_HIP, "rt_render: copy back failed: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
+template <typename R>
+int primary_to_host(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t h, uint64_t seed, double time,
+                    uint32_t* prim_id, R* t, R* normal, R* uv, uint8_t* front_face) {
+  if (!s || !cam || !prim_id || !t || !normal) return fail(RT_ERR_BAD_ARG, "rt_primary_hits: null argument");
+  if (w < 2 || h < 2) return fail(RT_ERR_BAD_ARG, "rt_primary_hits: image must be at least 2x2");
+  HIP_TRY(hipSetDevice(s->device));
+  size_t n = (size_t)w * h;
+  DeviceBuffers tmp;
+  auto alloc = [&](size_t bytes, void** out) -> hipError_t {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess) tmp.ptrs.push_back(*out);
+    return e;
+  };
+  uint32_t* d_id = nullptr;
+  R *d_t = nullptr, *d_n = nullptr, *d_uv = nullptr;
+  uint8_t* d_ff = nullptr;
+  HIP_TRY(alloc(n * sizeof(uint32_t), (void**)&d_id));
+  HIP_TRY(alloc(n * sizeof(R), (void**)&d_t));
+  HIP_TRY(alloc(n * 3 * sizeof(R), (void**)&d_n));
+  if (uv) HIP_TRY(alloc(n * 2 * sizeof(R), (void**)&d_uv));
+  if (front_face) HIP_TRY(alloc(n, (void**)&d_ff));
+  LaunchShape sh = make_shape(s, w, h, 1);
+  HIP_TRY(Side<R>::primary(Side<R>::get(s).view, to_camera<R>(*cam), w, h, seed, (R)time, d_id, d_t, d_n, d_uv, d_ff, sh,
+                           nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(prim_id, d_id, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(t, d_t, n * sizeof(R), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(normal, d_n, n * 3 * sizeof(R), hipMemcpyDeviceToHost));
+  if (uv) HIP_TRY(hipMemcpy(uv, d_uv, n * 2 * sizeof(R), hipMemcpyDeviceToHost));
+  if (front_face) HIP_TRY(hipMemcpy(front_face, d_ff, n, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_primary_hits(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t h, uint64_t seed, double time,
+                    uint32_t* prim_id, float* t, float* normal, float* uv, uint8_t* front_face) {
+  return primary_to_host<float>(s, cam, w, h, seed, time, prim_id, t, normal, uv, front_face);
+}
+int rt_primary_hits_f64(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t h, uint64_t seed, double time,
+                        uint32_t* prim_id, double* t, double* normal, double* uv, uint8_t* front_face) {
+  return primary_to_host<double>(s, cam, w, h, seed, time, prim_id, t, normal, uv, front_face);
+}
+
+int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* p, float* accum, rt_stats* stats) {
+  return render_to_host<float>(s, cam, p, accum, stats);
+}
+int rt_render_f64(rt_scene* s, const rt_camera* cam, const rt_params* p, double* accum, rt_stats* stats) {
+  return render_to_host<double>(s, cam, p, accum, stats);
+}
+int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* p, float* d_accum, int accumulate,
+                     void* stream, rt_stats* stats) {
+  return render_on_device<float>(s, cam, p, d_accum, accumulate, (hipStream_t)stream, stats);
+}
+
+void rt_tonemap(const float* accum, uint64_t n_pixels, uint64_t spp, uint8_t* rgb8) {
+  if (!accum || !rgb8) return;
+  const float inv = 1.0f / (float)spp;
+  for (uint64_t i = 0; i < 3 * n_pixels; ++i) {
+    float g = std::sqrt(accum[i] * inv);
+    uint8_t q = 0;
+    if (g == g) {
+      g = g < 0.0f ? 0.0f : (g > 0.9999f ? 0.9999f : g);
+      q = (uint8_t)(g * 256.0f);
+    }
+    rgb8[i] = q;
+  }
+}
+
+int rt_tonemap_device(int device, const float* d_accum, uint64_t n_pixels, uint64_t spp, uint8_t* d_rgb8, void* stream) {
+  if (!d_accum || !d_rgb8 || spp == 0) return fail(RT_ERR_BAD_ARG, "rt_tonemap_device: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(launch_tonemap(d_accum, 3 * n_pixels, 1.0f / (float)spp, d_rgb8, (hipStream_t)stream));
+  return RT_OK;
+}
+
+static int kat_common(int device, size_t in_bytes[], const void* in[], int n_in, size_t out_bytes, void* out,
+                      hipError_t (*run)(void** d_in, void* d_out, void* ctx), void* ctx) {
+  HIP_TRY(hipSetDevice(device));
+  DeviceBuffers tmp;
+  void* d_in[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < n_in; ++i) {
+    HIP_TRY(hipMalloc(&d_in[i], std::max<size_t>(in_bytes[i], 16)));
+    tmp.ptrs.push_back(d_in[i]);
+    HIP_TRY(hipMemcpy(d_in[i], in[i], in_bytes[i], hipMemcpyHostToDevice));
+  }
+  void* d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_out, std::max<size_t>(out_bytes, 16)));
+  tmp.ptrs.push_back(d_out);
+  HIP_TRY(run(d_in, d_out, ctx));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+struct KatCtx {
+  uint32_t n;
+  int use_f32;
+};
+
+int rt_kat_sphere_uv(int device, uint32_t n, const double* p, double* uv, int use_f32) {
+  if (!p || !uv || n == 0) return fail(RT_ERR_BAD_ARG, "rt_kat_sphere_uv: bad argument");
+  size_t ib[] = {n * 3 * sizeof(double)};
+  const void* in[] = {p};
+  KatCtx c{n, use_f32};
+  return kat_common(device, ib, in, 1, n * 2 * sizeof(double), uv,
+                    [](void** di, void* dout, void* ctx) -> hipError_t {
+                      auto* k = (KatCtx*)ctx;
+                      return k->use_f32 ? launch_kat_sphere_uv_f32(k->n, (const double*)di[0], (double*)dout, nullptr)
+                                        : launch_kat_sphere_uv_f64(k->n, (const double*)di[0], (double*)dout, nullptr);
+                    },
+                    &c);
+}
+
+int rt_kat_rotate(int device, uint32_t n, const double* angle, const double* axis, const double* v, double* out,
+                  int use_f32) {
+  if (!angle || !axis || !v || !out || n == 0) return fail(RT_ERR_BAD_ARG, "rt_kat_rotate: bad argument");
+  size_t ib[] = {n * sizeof(double), n * 3 * sizeof(double), n * 3 * sizeof(double)};
+  const void* in[] = {angle, axis, v};
+  KatCtx c{n, use_f32};
+  return kat_common(device, ib, in, 3, n * 3 * sizeof(double), out,
+                    [](void** di, void* dout, void* ctx) -> hipError_t {
+                      auto* k = (KatCtx*)ctx;
+                      return k->use_f32 ? launch_kat_rotate_f32(k->n, (const double*)di[0], (const double*)di[1],
+                                                                (const double*)di[2], (double*)dout, nullptr)
+                                        : launch_kat_rotate_f64(k->n, (const double*)di[0], (const double*)di[1],
+                                                                (const double*)di[2], (double*)dout, nullptr);
+                    },
+                    &c);
+}
+
+int rt_kat_philox(int device, uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+  if (!ctr || !key || !out || n == 0) return fail(RT_ERR_BAD_ARG, "rt_kat_philox: bad argument");
+  size_t ib[] = {n * 4 * sizeof(uint32_t), n * 2 * sizeof(uint32_t)};
+  const void* in[] = {ctr, key};
+  KatCtx c{n, 0};
+  return kat_common(device, ib, in, 2, n * 4 * sizeof(uint32_t), out,
+                    [](void** di, void* dout, void* ctx) -> hipError_t {
+                      auto* k = (KatCtx*)ctx;
+                      return launch_kat_philox(k->n, (const uint32_t*)di[0], (const uint32_t*)di[1], (uint32_t*)dout,
+                                               nullptr);
+                    },
+                    &c);
+}
+
+}  // extern "C"

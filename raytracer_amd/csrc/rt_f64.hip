@@ -1,0 +1,6 @@
+// Audit precision: the same kernels in f64, built with -ffp-contract=off so that they are
+// draw-for-draw and branch-for-branch comparable with the CPU oracle.  Not a production path.
+#define RT_SUFFIX f64
+#define RT_REAL double
+#define RT_EARLY_EXIT false
+#include "launch_impl.hpp"

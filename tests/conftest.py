@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+# (scene id, aspect ratio, n, max_depth) — every scene of scenes.rs plus the three config scenes
+SCENES = {
+    "random_scene": (0, 16.0 / 9.0, 0, 50),
+    "two_spheres": (1, 1.5, 0, 5),
+    "earth": (2, 1.5, 0, 5),
+    "simple_light": (3, 1.5, 0, 5),
+    "cube_scene": (4, 1.5, 0, 5),
+    "small_scene": (5, 1.5, 0, 5),
+    "cornell_box": (6, 1.0, 0, 50),
+    "bvh_stress": (7, 16.0 / 9.0, 20000, 50),
+    "final_scene": (8, 1.0, 0, 50),
+}
+
+
+@pytest.fixture(scope="session")
+def earthmap():
+    import raytracer_amd as R
+    return R.load_earthmap()

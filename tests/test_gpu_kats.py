@@ -1,0 +1,62 @@
+"""The reference's own known-answer vectors (tests/golden/reference_kats.json) evaluated by the
+DEVICE functions through the C ABI, in both precisions, plus Philox KATs on the device."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("use_f32", [0, 1])
+def test_device_get_sphere_uv(use_f32):
+    from raytracer_amd import _ffi as F
+    p = np.array([k["p"] for k in KATS["get_sphere_uv"]], dtype=np.float64)
+    want = np.array([k["uv"] for k in KATS["get_sphere_uv"]], dtype=np.float64)
+    uv = np.zeros_like(want)
+    F.check_hip(F.hip.rt_kat_sphere_uv(0, len(p), _ptr(p), _ptr(uv), use_f32))
+    tol = 1e-6 if use_f32 else KATS["tolerance"]  # f32 cannot reach the reference's 1e-8
+    assert np.abs(uv - want).max() < tol
+
+
+@pytest.mark.parametrize("use_f32", [0, 1])
+def test_device_rotate(use_f32):
+    from raytracer_amd import _ffi as F
+    ks = KATS["rotate"]
+    rng = np.random.default_rng(0)
+    ident = rng.uniform(*KATS["rotate_identity"]["angle_range_rad"], size=64)
+    angle = np.array([math.radians(k["angle_deg"]) for k in ks] + list(ident))
+    axis = np.array([k["axis"] for k in ks] + [KATS["rotate_identity"]["axis"]] * 64, dtype=np.float64)
+    v = np.array([k["p"] for k in ks] + [KATS["rotate_identity"]["p"]] * 64, dtype=np.float64)
+    want = np.array([k["result"] for k in ks] + [KATS["rotate_identity"]["p"]] * 64, dtype=np.float64)
+    out = np.zeros_like(want)
+    F.check_hip(F.hip.rt_kat_rotate(0, len(angle), _ptr(angle), _ptr(axis), _ptr(v), _ptr(out), use_f32))
+    tol = 1e-6 if use_f32 else KATS["tolerance"]
+    assert np.abs(out - want).max() < tol
+
+
+def test_device_philox():
+    from raytracer_amd import _ffi as F
+    import oracle_ffi as O
+    ks = KATS["philox4x32_10"]
+    rng = np.random.default_rng(1)
+    extra = 1000
+    ctr = np.concatenate([np.array([k["ctr"] for k in ks], dtype=np.uint32),
+                          rng.integers(0, 2**32, size=(extra, 4), dtype=np.uint64).astype(np.uint32)])
+    key = np.concatenate([np.array([k["key"] for k in ks], dtype=np.uint32),
+                          rng.integers(0, 2**32, size=(extra, 2), dtype=np.uint64).astype(np.uint32)])
+    out = np.zeros_like(ctr)
+    F.check_hip(F.hip.rt_kat_philox(0, len(ctr), _ptr(ctr), _ptr(key), _ptr(out)))
+    for i, k in enumerate(ks):
+        assert list(out[i]) == k["out"]
+    for i in range(len(ks), len(ctr)):
+        assert np.array_equal(out[i], O.philox(ctr[i], key[i]))

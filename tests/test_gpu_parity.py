@@ -1,0 +1,115 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs (sizes the oracle finishes in seconds).
+
+Three levels (BASELINE.json north_star):
+  1. primary-ray hit primitive ids: bit-exact for the f64 audit kernels; the f32 production
+     kernels may differ only on silhouette pixels (bounded fraction).
+  2. primary-ray t and normals within 1e-5 relative (f32), 1e-12 (f64 audit).
+  3. images: the f64 audit kernel follows the oracle path-for-path (same Philox words, same
+     branches), so low-spp images agree to rounding; the f32 production kernel agrees within
+     Monte-Carlo noise (PSNR / RMSE bounds written at each test).
+"""
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+pytestmark = pytest.mark.gpu
+
+W = 64
+
+
+def _pair(name, earthmap):
+    import oracle_ffi as O
+    import raytracer_amd as R
+    sid, asp, n, depth = SCENES[name]
+    hs = R.HostScene(sid, asp, n=n)
+    ds = R.DeviceScene(hs, 0)
+    os_ = O.OracleScene(sid, asp, n=n, texels=earthmap)
+    h = R.image_height(W, asp)
+    return hs, ds, os_, h, depth
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_primary_hits_f64_exact(name, earthmap):
+    hs, ds, os_, h, _ = _pair(name, earthmap)
+    for time in (0.0, 0.625):
+        gid, gt, gn, guv, gff = ds.primary_hits(W, h, seed=3, time=time, f64=True)
+        oid, ot, on, ouv, off = os_.primary_hits(W, h, seed=3, time=time)
+        assert np.array_equal(gid, oid), f"{name}: {(gid != oid).sum()} primary ids differ"
+        hit = oid != 0xFFFFFFFF
+        assert np.array_equal(gff[hit], off[hit])
+        # same operations in the same order with contraction off: only libm (sin/cos/acos/atan2/log)
+        # may differ in the last ulp
+        np.testing.assert_allclose(gt[hit], ot[hit], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(gn[hit], on[hit], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(guv[hit], ouv[hit], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_primary_hits_f32(name, earthmap):
+    hs, ds, os_, h, _ = _pair(name, earthmap)
+    gid, gt, gn, guv, gff = ds.primary_hits(W, h, seed=3, time=0.25, f64=False)
+    oid, ot, on, ouv, off = os_.primary_hits(W, h, seed=3, time=0.25)
+    same = gid == oid
+    # f32 rounding may move a silhouette by a fraction of a pixel: allow <= 0.5 % of pixels
+    assert (~same).mean() <= 0.005, f"{name}: {(~same).sum()} of {same.size} primary ids differ"
+    hit = same & (oid != 0xFFFFFFFF)
+    rel_t = np.abs(gt[hit] - ot[hit]) / np.abs(ot[hit])
+    dn = np.abs(gn[hit] - on[hit]).max(axis=-1)
+    # north_star level 2: 1e-5 relative.  Report the worst case, require it on >= 99.5 % of pixels and
+    # 1e-3 everywhere (grazing hits on the r=1000 ground sphere lose digits to cancellation in f32).
+    print(f"{name}: f32 primary t rel err max {rel_t.max() if rel_t.size else 0:.3g} "
+          f"p99.5 {np.quantile(rel_t, 0.995) if rel_t.size else 0:.3g}; normal abs err max {dn.max() if dn.size else 0:.3g}")
+    if rel_t.size:
+        assert np.quantile(rel_t, 0.995) <= 1e-5
+        assert rel_t.max() <= 1e-3
+        assert np.quantile(dn, 0.995) <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["random_scene", "two_spheres", "earth", "simple_light", "cube_scene",
+                                  "small_scene", "cornell_box", "final_scene"])
+def test_render_f64_follows_oracle_path_for_path(name, earthmap):
+    hs, ds, os_, h, depth = _pair(name, earthmap)
+    spp = 8
+    g, gst = ds.render(W, h, spp, depth, seed=11, sample_offset=5, stats=True, f64=True)
+    o, ocnt, _ = os_.render(W, h, spp, depth, seed=11, sample_offset=5)
+    fin = np.isfinite(o) & np.isfinite(g)
+    assert (np.isfinite(o) == np.isfinite(g)).mean() >= 0.999
+    err = np.abs(g - o)[fin] / (1.0 + np.abs(o[fin]))
+    # same draws, same branches; differences come from last-ulp libm results and the iterative vs
+    # recursive product order — except for the rare path where such an ulp flips a branch
+    assert np.quantile(err, 0.999) <= 1e-9, f"{name}: err q99.9 {np.quantile(err, 0.999)}"
+    assert (err > 1e-9).mean() <= 1e-3
+    # identical work counters (the audit kernel does not early-exit)
+    for k in ("rays", "nodes_visited", "sphere_tests", "cube_tests", "closest_hits", "diffuse_vertices",
+              "specular_vertices", "emitter_hits", "misses", "light_probes", "medium_probes"):
+        assert abs(gst[k] - ocnt[k]) <= 1e-4 * max(1, ocnt[k]), (name, k, gst[k], ocnt[k])
+
+
+def _psnr(a, b):
+    mse = np.mean((a - b) ** 2)
+    return 10 * np.log10(1.0 / mse) if mse > 0 else np.inf
+
+
+@pytest.mark.parametrize("name", ["random_scene", "simple_light", "cornell_box", "earth", "small_scene"])
+def test_render_f32_within_monte_carlo_noise(name, earthmap):
+    """f32 production kernel vs oracle, different seeds, matched spp: the difference of two
+    independent estimates must look like noise of the measured per-pixel variance."""
+    hs, ds, os_, h, depth = _pair(name, earthmap)
+    spp = 256
+    g, gst = ds.render(W, h, spp, depth, seed=21)
+    o1, _, _ = os_.render(W, h, spp, depth, seed=22)
+    o2, _, _ = os_.render(W, h, spp, depth, seed=23)
+    g = g.astype(np.float64) / spp
+    o1 /= spp
+    o2 /= spp
+    fin = np.isfinite(g) & np.isfinite(o1) & np.isfinite(o2)
+    # oracle-vs-oracle difference estimates the noise floor; gpu-vs-oracle must not exceed it by much
+    d_ref = np.sqrt(np.mean((np.clip(o1, 0, 1) - np.clip(o2, 0, 1))[fin] ** 2))
+    d_gpu = np.sqrt(np.mean((np.clip(g, 0, 1) - np.clip(o1, 0, 1))[fin] ** 2))
+    mean_ratio = g[fin].mean() / o1[fin].mean()
+    print(f"{name}: rmse gpu-vs-oracle {d_gpu:.4g}, oracle-vs-oracle {d_ref:.4g}, mean ratio {mean_ratio:.4f}, "
+          f"nonfinite samples {gst['nonfinite_samples']}")
+    assert d_gpu <= 1.25 * d_ref + 1e-4
+    assert abs(mean_ratio - 1.0) <= 0.02
