@@ -115,7 +115,8 @@ def _load(name):
     return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
-hip = _load("librt_hip.so")
+# RT_HIP_LIBNAME: developer switch for A/B-ing kernel builds (tools/build_variant.sh); default = the product
+hip = _load(os.environ.get("RT_HIP_LIBNAME", "librt_hip.so"))
 host = _load("librt_host.so")
 
 hip.rt_last_error.restype = C.c_char_p

@@ -22,11 +22,11 @@ template <bool STATS> struct Cnt {
 #pragma unroll
     for (int i = 0; i < (STATS ? (int)ST_COUNT : 1); ++i) v[i] = 0;
   }
-  template <int I> RT_DEV void inc() {
+  template <int I> RT_DEV void inc(uint32_t n = 1) {
     if constexpr (I == ST_RAYS)
-      ++v[0];
+      v[0] += n;
     else if constexpr (STATS)
-      ++v[I];
+      v[I] += n;
   }
 };
 
@@ -96,9 +96,10 @@ RT_DEV bool sphere_t<float>(Vec3<float> o, Vec3<float> d, float a, Vec3<float> c
   const double disc = half_b * half_b - a64 * cc;
   if (disc < 0.0) return false;
   const double sqrtd = (double)sqrtf((float)disc);
-  float root = (float)(-half_b - sqrtd) / a;
+  const float inv_a = rrcp(a);
+  float root = (float)(-half_b - sqrtd) * inv_a;
   if (root < t_min || root > t_max) {
-    root = (float)(-half_b + sqrtd) / a;
+    root = (float)(-half_b + sqrtd) * inv_a;
     if (root < t_min || root > t_max) return false;
   }
   t_out = root;
@@ -122,7 +123,7 @@ RT_DEV Vec3<float> sphere_outward<float>(Vec3<float> o, Vec3<float> d, float t, 
 // hittable.rs:66-72
 template <typename R> RT_DEV Vec3<R> moving_center(const MSphere<R>& m, R time) {
   Vec3<R> c0(m.c0[0], m.c0[1], m.c0[2]), c1(m.c1[0], m.c1[1], m.c1[2]);
-  return c0 + ((time - m.t0) / (m.t1 - m.t0)) * (c1 - c0);
+  return c0 + rdiv(time - m.t0, m.t1 - m.t0) * (c1 - c0);
 }
 
 // One simple primitive (SPHERE / MSPHERE / CUBE) against a ray in that primitive's frame.
@@ -153,7 +154,20 @@ RT_DEV bool prim_t(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, Vec3<
   }
 }
 
-template <typename R> RT_DEV Vec3<R> inverse3(Vec3<R> d) { return {R(1) / d.x, R(1) / d.y, R(1) / d.z}; }
+template <typename R> RT_DEV Vec3<R> inverse3(Vec3<R> d) { return {rrcp(d.x), rrcp(d.y), rrcp(d.z)}; }
+
+template <typename R> RT_DEV Vec3<R> xf_dir(const R* m, Vec3<R> v) {
+  return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z,
+          m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+template <typename R> RT_DEV Vec3<R> xf_point(const R* m, const R* b, Vec3<R> v) {
+  return {m[0] * v.x + m[1] * v.y + m[2] * v.z + b[0], m[3] * v.x + m[4] * v.y + m[5] * v.z + b[1],
+          m[6] * v.x + m[7] * v.y + m[8] * v.z + b[2]};
+}
+template <typename R> RT_DEV Vec3<R> xf_dir_transposed(const R* m, Vec3<R> v) {
+  return {m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z,
+          m[2] * v.x + m[5] * v.y + m[8] * v.z};
+}
 
 // A chain of Translate / Rotate / ConstantMedium wrappers around one primitive
 // (hittable.rs:319-386).  All wrappers are rigid, so t is the same in every frame.
@@ -164,6 +178,15 @@ RT_DEV bool complex_t(const SceneView<R>& sc, uint32_t idx, const RayT<R>& r, R 
   RayT<R> lr = r;
   Vec3<R> dm = r.d;  // direction in the medium's frame
   R neg_inv_density = R(0);
+  if constexpr (sizeof(R) == 4) {
+    const ComplexXf<R>& xf = sc.complex_xf[idx];
+    cnt.template inc<ST_TRANSLATE>(cx.n_translate);
+    cnt.template inc<ST_ROTATE>(cx.n_rotate);
+    if (cx.medium_pos != REF_NONE) cnt.template inc<ST_MEDIUM>();
+    lr.o = xf_point(xf.m_full, xf.b_full, r.o);
+    lr.d = xf_dir(xf.m_full, r.d);
+    neg_inv_density = xf.neg_inv_density;  // |dm| = |r.d|: the maps are rigid
+  } else
   for (uint32_t k = 0; k < cx.op_count; ++k) {
     uint32_t tag = sc.op_tag[cx.op_first + k];
     Op<R> op = sc.ops[cx.op_first + k];
@@ -199,7 +222,7 @@ RT_DEV bool complex_t(const SceneView<R>& sc, uint32_t idx, const RayT<R>& r, R 
   R distance_inside_boundary = (t2 - t1) * ray_length;
   R hit_distance = neg_inv_density * rlog(rng.next<R>());
   if (hit_distance > distance_inside_boundary) return false;
-  t_out = t1 + hit_distance / ray_length;
+  t_out = t1 + rdiv(hit_distance, ray_length);
   return true;
 }
 
@@ -259,7 +282,7 @@ RT_DEV void face_normal(Vec3<R> d, Vec3<R> outward, HitRec<R>& h) {  // hittable
 }
 
 template <typename R>
-RT_DEV void prim_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, R t, HitRec<R>& h) {
+RT_DEV void prim_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, R t, bool force_uv, HitRec<R>& h) {
   uint32_t kind = ref_kind(ref), idx = ref_index(ref);
   h.p = r.o + t * r.d;  // Ray::at, ray.rs:19-21
   if (kind == LEAF_CUBE) {  // hittable.rs:229-255
@@ -288,6 +311,7 @@ RT_DEV void prim_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, 
     R az = rabs(n.z), ax = rabs(n.x), ay = rabs(n.y);
     h.uv.x = rel.x * az + rel.y * ax + rel.x * ay;
     h.uv.y = rel.y * az + rel.z * ax + rel.z * ay;
+    (void)force_uv;
     face_normal(r.d, n, h);
   } else {  // hittable.rs:277-286 / 308-317
     Vec3<R> c;
@@ -307,18 +331,46 @@ RT_DEV void prim_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, 
     h.material = at.material;
     h.object = at.object;
     Vec3<R> outward = sphere_outward(r.o, r.d, t, h.p, c, radius);
-    h.uv = get_sphere_uv(outward);
+    // get_sphere_uv costs an acos and an atan2: evaluate it only when some texture reads uv
+    if (force_uv || (sc.materials[at.material].flags & MATF_NEEDS_UV)) {
+      h.uv = get_sphere_uv(outward);
+    } else {
+      h.uv.x = R(0);
+      h.uv.y = R(0);
+    }
     face_normal(r.d, outward, h);
   }
 }
 
 template <typename R>
-RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, R t, HitRec<R>& h) {
+RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, R t, bool force_uv,
+                            HitRec<R>& h) {
   if (ref_kind(ref) != LEAF_COMPLEX) {
-    prim_record(sc, ref, r, t, h);
+    prim_record(sc, ref, r, t, force_uv, h);
     return;
   }
   Complex cx = sc.complexes[ref_index(ref)];
+  if constexpr (sizeof(R) == 4) {
+    const ComplexXf<R>& xf = sc.complex_xf[ref_index(ref)];
+    RayT<R> lr;
+    lr.time = r.time;
+    if (cx.medium_pos == REF_NONE) {
+      lr.o = xf_point(xf.m_full, xf.b_full, r.o);
+      lr.d = xf_dir(xf.m_full, r.d);
+      prim_record(sc, cx.body, lr, t, force_uv, h);
+      h.normal = xf_dir_transposed(xf.m_full, h.normal);
+    } else {
+      lr.d = xf_dir(xf.m_outer, r.d);
+      h.uv.x = R(0);
+      h.uv.y = R(0);
+      face_normal(lr.d, Vec3<R>(1, 0, 0), h);
+      h.normal = xf_dir_transposed(xf.m_outer, h.normal);
+      h.material = cx.material;
+    }
+    h.object = cx.object;
+    h.p = r.o + t * r.d;  // rigid maps: the world-space point is o + t d in any frame
+    return;
+  }
   RayT<R> lr = r;
   uint32_t n_outer = cx.medium_pos == REF_NONE ? cx.op_count : cx.medium_pos;
   for (uint32_t k = 0; k < n_outer; ++k) {
@@ -333,7 +385,7 @@ RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>&
     }
   }
   if (cx.medium_pos == REF_NONE) {
-    prim_record(sc, cx.body, lr, t, h);
+    prim_record(sc, cx.body, lr, t, force_uv, h);
   } else {  // hittable.rs:349-362: arbitrary normal (1,0,0), uv (0,0), in the medium's frame
     h.p = lr.o + t * lr.d;
     h.uv.x = R(0);

@@ -15,6 +15,9 @@
 namespace rt {
 
 constexpr int BLOCK = 256;
+#ifndef RT_RENDER_MIN_WAVES
+#define RT_RENDER_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
+#endif
 
 // ---- texture.rs:33-69 ---------------------------------------------------------------------
 template <typename R>
@@ -23,7 +26,8 @@ RT_DEV Vec3<R> texture_value(const SceneView<R>& sc, uint32_t idx, Vec2<R> uv, V
     Texture<R> t = sc.textures[idx];
     if (t.tag == TEX_CHECKER) {
       const R scale = R(10);
-      R sines = rsin(scale * p.x) * rsin(scale * p.y) * rsin(scale * p.z);
+      (void)scale;
+      R sines = sin_scaled10(p.x) * sin_scaled10(p.y) * sin_scaled10(p.z);
       idx = sines < R(0) ? t.odd : t.even;
       continue;
     }
@@ -67,18 +71,20 @@ template <typename R> RT_DEV Vec3<R> random_cosine_direction(Rng& rng) {
   R r1 = rng.next<R>();
   R r2 = rng.next<R>();
   R z = rroot(R(1) - r2);
-  R phi = R(2) * Consts<R>::pi * r1;
-  R x = rcos(phi) * rroot(r2);
-  R y = rsin(phi) * rroot(r2);
+  R sn, cs;
+  sincos_2pi(r1, sn, cs);
+  R x = cs * rroot(r2);
+  R y = sn * rroot(r2);
   return Vec3<R>(x, y, z);
 }
 template <typename R> RT_DEV Vec3<R> random_to_sphere(Rng& rng, R radius, R distance_squared) {
   R r1 = rng.next<R>();
   R r2 = rng.next<R>();
-  R z = R(1) + r2 * (rroot(R(1) - radius * radius / distance_squared) - R(1));
-  R phi = R(2) * Consts<R>::pi * r1;
-  R x = rcos(phi) * rroot(R(1) - z * z);
-  R y = rsin(phi) * rroot(R(1) - z * z);
+  R z = R(1) + r2 * (rroot(R(1) - rdiv(radius * radius, distance_squared)) - R(1));
+  R sn, cs;
+  sincos_2pi(r1, sn, cs);
+  R x = cs * rroot(R(1) - z * z);
+  R y = sn * rroot(R(1) - z * z);
   return Vec3<R>(x, y, z);
 }
 
@@ -104,14 +110,14 @@ RT_DEV R light_pdf_one(const Light<R>& l, Vec3<R> origin, Vec3<R> direction, Cnt
   R t;
   if (!sphere_t(origin, direction, sqrlen(direction), c, l.radius, R(0), Consts<R>::inf, t)) return R(0);
   cnt.template inc<ST_SPHERE_HITS>();
-  R cos_theta_max = rroot(R(1) - l.radius * l.radius / sqrlen(c - origin));
+  R cos_theta_max = rroot(R(1) - rdiv(l.radius * l.radius, sqrlen(c - origin)));
   R solid_angle = R(2) * Consts<R>::pi * (R(1) - cos_theta_max);
-  return R(1) / solid_angle;
+  return rrcp(solid_angle);
 }
 template <typename R, bool STATS>
 RT_DEV R lights_pdf(const SceneView<R>& sc, Vec3<R> origin, Vec3<R> direction, Cnt<STATS>& cnt) {
   if (sc.lights_kind == LIGHTS_SINGLE) return light_pdf_one(sc.lights[0], origin, direction, cnt);
-  R weight = R(1) / (R)sc.n_lights;
+  R weight = rrcp((R)sc.n_lights);
   R sum = R(0);
   for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf_one(sc.lights[i], origin, direction, cnt);
   return sum;
@@ -119,7 +125,7 @@ RT_DEV R lights_pdf(const SceneView<R>& sc, Vec3<R> origin, Vec3<R> direction, C
 
 // material.rs:128-133
 template <typename R> RT_DEV R reflectance(R cosine, R ref_idx) {
-  R r0 = (R(1) - ref_idx) / (R(1) + ref_idx);
+  R r0 = rdiv(R(1) - ref_idx, R(1) + ref_idx);
   r0 = r0 * r0;
   R m = R(1) - cosine;
   R m2 = m * m;
@@ -142,7 +148,7 @@ RT_DEV bool shade(const SceneView<R>& sc, const HitRec<R>& h, RayT<R>& ray, Vec3
   if (m.tag == MAT_DIELECTRIC) {  // material.rs:66-87; emitted is dropped (main.rs:81-83)
     cnt.template inc<ST_SPECULAR>();
     R ir = m.p[0];
-    R refraction_ratio = h.front_face ? R(1) / ir : ir;
+    R refraction_ratio = h.front_face ? rrcp(ir) : ir;
     Vec3<R> unit_direction = normalize(ray.d);
     R cos_theta = rmin(dot(-unit_direction, h.normal), R(1));
     R sin_theta = rroot(R(1) - cos_theta * cos_theta);
@@ -180,7 +186,7 @@ RT_DEV bool shade(const SceneView<R>& sc, const HitRec<R>& h, RayT<R>& ray, Vec3
   // pdf.rs:13-31
   Vec3<R> unit = normalize(direction);
   R cosine = dot(unit, uvw.w);
-  R cos_pdf = cosine <= R(0) ? R(0) : cosine / Consts<R>::pi;
+  R cos_pdf = cosine <= R(0) ? R(0) : rdiv(cosine, Consts<R>::pi);
   R pdf_value;
   if (have_lights) {
     pdf_value = R(0);
@@ -193,7 +199,7 @@ RT_DEV bool shade(const SceneView<R>& sc, const HitRec<R>& h, RayT<R>& ray, Vec3
   R spdf = R(1);
   if (m.tag == MAT_LAMBERTIAN) {
     R c2 = dot(h.normal, unit);
-    spdf = c2 <= R(0) ? R(0) : c2 / Consts<R>::pi;
+    spdf = c2 <= R(0) ? R(0) : rdiv(c2, Consts<R>::pi);
   }
   thr = thr * ((attenuation * spdf) / pdf_value);  // main.rs:93-97
   ray.o = h.p;
@@ -255,7 +261,7 @@ struct RenderArgs {
 };
 
 template <typename R, bool STATS, bool EARLY_EXIT>
-__global__ void __launch_bounds__(BLOCK) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
+__global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
                                                        R* __restrict__ accum, DeviceStats* stats) {
   extern __shared__ uint32_t lds_stack[];
   uint32_t* stack = lds_stack + threadIdx.x;
@@ -288,8 +294,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneView<R> sc, CameraVi
         rng.begin(0);
         R ju = rng.next<R>();
         R jv = rng.next<R>();
-        R u = ((R)px + ju) / (R)(a.width - 1);                  // main.rs:161
-        R v = ((R)(a.height - py - 1) + jv) / (R)(a.height - 1);  // main.rs:162-163
+        R u = rdiv((R)px + ju, (R)(a.width - 1));                  // main.rs:161
+        R v = rdiv((R)(a.height - py - 1) + jv, (R)(a.height - 1));  // main.rs:162-163
         ray = camera_ray(cam, u, v, rng);
         thr = Vec3<R>(1, 1, 1);
         L = Vec3<R>(0, 0, 0);
@@ -314,7 +320,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneView<R> sc, CameraVi
       } else {
         cnt.template inc<ST_CLOSEST>();
         HitRec<R> h;
-        make_hit_record(sc, best, ray, t, h);
+        make_hit_record(sc, best, ray, t, false, h);
         cont = shade(sc, h, ray, thr, L, rng, cnt);
       }
       ++slot;
@@ -382,7 +388,7 @@ __global__ void __launch_bounds__(BLOCK) primary_kernel(SceneView<R> sc, CameraV
   h.normal = Vec3<R>(0, 0, 0);
   h.uv.x = h.uv.y = R(0);
   h.front_face = false;
-  if (best != REF_NONE) make_hit_record(sc, best, ray, t, h);
+  if (best != REF_NONE) make_hit_record(sc, best, ray, t, true, h);
   prim_id[pixel] = h.object;
   t_out[pixel] = t;
   normal[3ull * pixel + 0] = h.normal.x;

@@ -52,13 +52,23 @@ struct Attr {  // cold per-primitive attributes
 };
 struct Complex {
   uint32_t body, op_first, op_count, medium_pos;  // medium_pos = index of the MEDIUM op in the chain, or REF_NONE
-  uint32_t material, object, pad0, pad1;
+  uint32_t material, object, n_rotate, n_translate;
+};
+// The wrapper chain of a complex object composed on the host (in f64) into rigid maps
+// local = M * world + b.  `full` takes a world ray into the primitive's frame, `outer` into the
+// constant medium's frame (= full when there is no medium).  Used by the f32 kernels; the f64
+// audit kernels walk the chain op by op with Hamilton products exactly like hittable.rs:364-386.
+template <typename R> struct alignas(16) ComplexXf {
+  R m_full[9], b_full[3];
+  R m_outer[9], b_outer[3];
+  R neg_inv_density, pad[3];
 };
 template <typename R> struct alignas(4 * sizeof(R)) Op {
   R d[4];  // offset xyz | quaternion wxyz | neg_inv_density
 };
+constexpr uint32_t MATF_NEEDS_UV = 1u;  // some texture below this material reads hit.uv (Image / UV)
 template <typename R> struct Material {
-  uint32_t tag, texture;
+  uint32_t tag, texture, flags, pad;
   R p[4];
 };
 template <typename R> struct Texture {
@@ -80,6 +90,7 @@ template <typename R> struct SceneView {
   const Attr* msphere_attr;
   const Attr* cube_attr;
   const Complex* complexes;
+  const ComplexXf<R>* complex_xf;
   const uint32_t* op_tag;
   const Op<R>* ops;
   const Material<R>* materials;

@@ -52,6 +52,22 @@ template <> double conv_hi<double>(double v) { return v; }
 template <> float conv_lo<float>(double v) { return conv_down(v); }
 template <> float conv_hi<float>(double v) { return conv_up(v); }
 
+void host_qrotate(const double v[3], const double q[4], double out[3]) {
+  auto ham = [](const double a[4], const double b[4], double r[4]) {
+    r[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    r[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    r[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    r[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  };
+  const double p[4] = {0.0, v[0], v[1], v[2]}, qi[4] = {q[0], -q[1], -q[2], -q[3]};
+  double t[4], r[4];
+  ham(q, p, t);
+  ham(t, qi, r);
+  out[0] = r[1];
+  out[1] = r[2];
+  out[2] = r[3];
+}
+
 struct DeviceBuffers {
   std::vector<void*> ptrs;
   ~DeviceBuffers() {
@@ -134,10 +150,18 @@ template <typename R> hipError_t build_side(const rt_scene_desc& d, const std::v
     op_tag[i] = d.op_tag[i];
     for (int k = 0; k < 4; ++k) ops[i].d[k] = conv<R>(d.op_data[4 * (size_t)i + k]);
   }
+  // which textures read hit.uv (validated acyclic: checker children have larger indices)
+  std::vector<uint8_t> tex_uv(d.n_textures, 0);
+  for (uint32_t i = d.n_textures; i-- > 0;) {
+    if (d.tex_tag[i] == RT_TEX_IMAGE || d.tex_tag[i] == RT_TEX_UV) tex_uv[i] = 1;
+    if (d.tex_tag[i] == RT_TEX_CHECKER) tex_uv[i] = tex_uv[d.tex_odd[i]] | tex_uv[d.tex_even[i]];
+  }
   std::vector<Material<R>> mats(d.n_materials);
   for (uint32_t i = 0; i < d.n_materials; ++i) {
     mats[i].tag = d.mat_tag[i];
     mats[i].texture = d.mat_texture[i];
+    mats[i].pad = 0;
+    mats[i].flags = (d.mat_texture[i] < d.n_textures && tex_uv[d.mat_texture[i]]) ? MATF_NEEDS_UV : 0u;
     for (int k = 0; k < 4; ++k) mats[i].p[k] = conv<R>(d.mat_params[4 * (size_t)i + k]);
   }
   std::vector<Texture<R>> texs(d.n_textures);
@@ -150,6 +174,58 @@ template <typename R> hipError_t build_side(const rt_scene_desc& d, const std::v
     texs[i].height = d.tex_height[i];
     texs[i].texel_offset = d.tex_texel_offset[i];
     for (int k = 0; k < 3; ++k) texs[i].color[k] = conv<R>(d.tex_color[3 * (size_t)i + k]);
+  }
+  // compose each complex object's wrapper chain into rigid maps (f64 on the host)
+  std::vector<ComplexXf<R>> xfs(d.n_complex);
+  for (uint32_t i = 0; i < d.n_complex; ++i) {
+    double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, b[3] = {0, 0, 0};
+    double Mo[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, bo[3] = {0, 0, 0};
+    double nid = 0.0;
+    for (uint32_t k = 0; k < complexes[i].op_count; ++k) {
+      const uint32_t o = complexes[i].op_first + k;
+      const double* q = d.op_data + 4 * (size_t)o;
+      if (d.op_tag[o] == RT_OP_TRANSLATE) {
+        for (int c = 0; c < 3; ++c) b[c] -= q[c];
+      } else if (d.op_tag[o] == RT_OP_ROTATE) {
+        // columns of the linear map v -> q v q* (alias.rs:112-117)
+        double Rm[9];
+        for (int c = 0; c < 3; ++c) {
+          double e[3] = {0, 0, 0};
+          e[c] = 1.0;
+          double r[3];
+          host_qrotate(e, q, r);
+          Rm[0 + c] = r[0];
+          Rm[3 + c] = r[1];
+          Rm[6 + c] = r[2];
+        }
+        double M2[9], b2[3];
+        for (int r_ = 0; r_ < 3; ++r_) {
+          for (int c = 0; c < 3; ++c)
+            M2[3 * r_ + c] = Rm[3 * r_] * M[c] + Rm[3 * r_ + 1] * M[3 + c] + Rm[3 * r_ + 2] * M[6 + c];
+          b2[r_] = Rm[3 * r_] * b[0] + Rm[3 * r_ + 1] * b[1] + Rm[3 * r_ + 2] * b[2];
+        }
+        std::memcpy(M, M2, sizeof(M));
+        std::memcpy(b, b2, sizeof(b));
+      } else {
+        std::memcpy(Mo, M, sizeof(M));
+        std::memcpy(bo, b, sizeof(b));
+        nid = q[0];
+      }
+    }
+    if (complexes[i].medium_pos == REF_NONE) {
+      std::memcpy(Mo, M, sizeof(M));
+      std::memcpy(bo, b, sizeof(b));
+    }
+    std::memset(&xfs[i], 0, sizeof(ComplexXf<R>));
+    for (int c = 0; c < 9; ++c) {
+      xfs[i].m_full[c] = conv<R>(M[c]);
+      xfs[i].m_outer[c] = conv<R>(Mo[c]);
+    }
+    for (int c = 0; c < 3; ++c) {
+      xfs[i].b_full[c] = conv<R>(b[c]);
+      xfs[i].b_outer[c] = conv<R>(bo[c]);
+    }
+    xfs[i].neg_inv_density = conv<R>(nid);
   }
   std::vector<uint8_t> texels(d.texels, d.texels + (d.texels ? d.n_texel_bytes : 0));
   std::vector<Light<R>> lights(d.n_lights);
@@ -170,6 +246,7 @@ template <typename R> hipError_t build_side(const rt_scene_desc& d, const std::v
   UP(msphere_attr, msphere_attr)
   UP(cube_attr, cube_attr)
   UP(complexes, complexes)
+  UP(xfs, complex_xf)
   UP(op_tag, op_tag)
   UP(ops, ops)
   UP(mats, materials)
@@ -312,6 +389,14 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
     for (uint32_t k = 0; k < c.op_count; ++k) {
       uint8_t tag = d->op_tag[c.op_first + k];
       NEED(tag <= RT_OP_MEDIUM, "bad op tag");
+      if (tag == RT_OP_ROTATE) {
+        const double* q = d->op_data + 4 * (size_t)(c.op_first + k);
+        const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        if (!(std::fabs(n2 - 1.0) <= 1e-9))
+          return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: complex %u has a non-unit rotation quaternion", i);
+        ++c.n_rotate;
+      }
+      if (tag == RT_OP_TRANSLATE) ++c.n_translate;
       if (tag == RT_OP_MEDIUM) {
         if (c.medium_pos != REF_NONE)
           return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: complex %u nests two constant media", i);
