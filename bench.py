@@ -158,7 +158,7 @@ def main():
         # roofline of the dominant kernel (render_kernel<float>): live HIP-event duration on the launch
         # stream, algorithmic work from a counted pass of the same launch shape at 16 spp
         st_c = ds.render_device(accum.data_ptr(), width, height, 16, args.max_depth, seed=1, sample_offset=0,
-                                spp_per_launch=16, stream=stream, stats=True)
+                                spp_per_launch=16, stream=stream, stats=True, force_bvh=True)
         flops_per_ray, bytes_per_ray = algorithmic_per_ray(st_c, width * height, st_c["launches"])
         avg_launch_ms = kernel_ms / max(1, launches)
         rays_per_launch = rays / max(1, launches)

@@ -159,7 +159,10 @@ typedef struct rt_camera {
   double lens_radius, time_open, time_close;
 } rt_camera;
 
-#define RT_FLAG_STATS 1u  /* count nodes / primitive tests / vertices (slower launch) */
+#define RT_FLAG_STATS 1u      /* count nodes / primitive tests / vertices (slower launch) */
+#define RT_FLAG_FORCE_BVH 2u  /* f32 only: always walk the BVH, even for scenes small enough for the
+                                 leaf-list fast path (same result; used to count the reference
+                                 algorithm's node visits for the roofline's algorithmic work) */
 
 typedef struct rt_params {
   uint32_t width, height;   /* image size; h = trunc(w / aspect) is the caller's job (main.rs:112) */

@@ -35,14 +35,18 @@ struct Camera {
     return c;
   }
 
-  // cam.rs:63-71 — draw order: disk (2 per rejection iteration), then time
+  // cam.rs:63-71.  One deliberate difference in DRAW ORDER (not in distribution): the shutter
+  // time is drawn before the lens-disk rejection loop instead of after it.  The rand stream is
+  // replaced anyway (north_star), the two quantities are independent, and the fixed position of
+  // the time draw lets the GPU skip the (unused) disk draws of a pinhole camera.
   Ray get_ray(double s, double t, Rng& rng) const {
+    const double time = rng.range(time_open, time_close);
     V3 rd = lens_radius * random_in_unit_disk(rng);
     V3 offset = u * rd.x + v * rd.y;
     Ray r;
     r.origin = origin + offset;
     r.direction = lower_left_corner + s * horizontal + t * vertical - origin - offset;
-    r.time = rng.range(time_open, time_close);
+    r.time = time;
     return r;
   }
 };

@@ -133,18 +133,18 @@ class DeviceScene:
                        _ptr(ff)))
         return ids, t, nrm, uv, ff
 
-    def _params(self, width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats):
+    def _params(self, width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh=False):
         p = F.RtParams()
         p.width, p.height, p.spp, p.max_depth = width, height, spp, max_depth
         p.seed, p.sample_offset = seed, sample_offset
         p.spp_per_launch = spp_per_launch
-        p.flags = F.RT_FLAG_STATS if stats else 0
+        p.flags = (F.RT_FLAG_STATS if stats else 0) | (F.RT_FLAG_FORCE_BVH if force_bvh else 0)
         return p
 
     def render(self, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0, stats=False,
-               f64=False, camera=None):
+               f64=False, camera=None, force_bvh=False):
         """The render closure main.rs:154-167 for every pixel: returns (accum SUM [h][w][3], stats dict)."""
-        p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats)
+        p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh)
         accum = np.zeros((height, width, 3), dtype=np.float64 if f64 else np.float32)
         st = F.RtStats()
         fn = F.hip.rt_render_f64 if f64 else F.hip.rt_render
@@ -153,9 +153,9 @@ class DeviceScene:
         return accum, st.as_dict()
 
     def render_device(self, accum_ptr, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0,
-                      accumulate=False, stream=None, want_stats=True, stats=False, camera=None):
+                      accumulate=False, stream=None, want_stats=True, stats=False, camera=None, force_bvh=False):
         """Same, into DEVICE memory (accum_ptr = raw device address of a float32 [h][w][3] buffer)."""
-        p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats)
+        p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh)
         st = F.RtStats()
         cam = camera if camera is not None else self.host.camera
         F.check_hip(F.hip.rt_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(accum_ptr),

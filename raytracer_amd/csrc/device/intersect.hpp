@@ -267,6 +267,35 @@ RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng
   }
 }
 
+// Small scenes (a handful of leaves): test every leaf in BVH left-first DFS order with the
+// same shrinking t_max and the same strict `<` — exactly the reference's List arm
+// (hittable.rs:387-399).  A leaf that the BVH would have pruned can only be hit outside
+// (t_min, closest), which its own test rejects (and a medium returns before drawing), so the
+// winner and the draw sequence equal the BVH walk's.  The loop counter is wave-uniform: every
+// lane tests the same leaf at the same time (no traversal divergence) and the compiler fetches
+// leaf data through the scalar cache.
+template <typename R, bool STATS>
+RT_DEV void traverse_linear(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, R& closest,
+                            uint32_t& best, Cnt<STATS>& cnt) {
+  closest = Consts<R>::inf;
+  best = REF_NONE;
+  const Vec3<R> inv_d = inverse3(r.d);
+  const R a = sqrlen(r.d);
+  for (uint32_t k = 0; k < sc.n_linear; ++k) {
+    const uint32_t cur = sc.linear[k];
+    R t;
+    bool h;
+    if (ref_kind(cur) == LEAF_COMPLEX)
+      h = complex_t(sc, ref_index(cur), r, t_min, closest, rng, t, cnt);
+    else
+      h = prim_t(sc, cur, r, inv_d, a, t_min, closest, t, cnt);
+    if (h && t < closest) {
+      closest = t;
+      best = cur;
+    }
+  }
+}
+
 // ---- the winner's HitRecord (hittable.rs:17-40) -------------------------------------------
 template <typename R> struct HitRec {
   Vec3<R> p, normal;
@@ -345,32 +374,45 @@ RT_DEV void prim_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, 
 template <typename R>
 RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, R t, bool force_uv,
                             HitRec<R>& h) {
+  if constexpr (sizeof(R) == 4) {
+    // f32: one shared copy of the primitive code for bare and wrapped primitives (lanes of a
+    // wave that hit a wall and lanes that hit a rotated box run the same cube code together).
+    const bool is_cx = ref_kind(ref) == LEAF_COMPLEX;
+    bool is_medium = false;
+    uint32_t body = ref, cx_material = 0, cx_object = 0;
+    const R* m = nullptr;
+    RayT<R> lr = r;
+    if (is_cx) {
+      const Complex cx = sc.complexes[ref_index(ref)];
+      const ComplexXf<R>& xf = sc.complex_xf[ref_index(ref)];
+      is_medium = cx.medium_pos != REF_NONE;
+      body = cx.body;
+      cx_material = cx.material;
+      cx_object = cx.object;
+      m = is_medium ? xf.m_outer : xf.m_full;
+      lr.o = xf_point(xf.m_full, xf.b_full, r.o);
+      lr.d = xf_dir(m, r.d);
+    }
+    if (!is_medium) {
+      prim_record(sc, body, lr, t, force_uv, h);
+    } else {  // hittable.rs:349-362: arbitrary normal (1,0,0), uv (0,0), in the medium's frame
+      h.uv.x = R(0);
+      h.uv.y = R(0);
+      face_normal(lr.d, Vec3<R>(1, 0, 0), h);
+      h.material = cx_material;
+    }
+    if (is_cx) {
+      h.normal = xf_dir_transposed(m, h.normal);
+      h.object = cx_object;
+    }
+    h.p = r.o + t * r.d;  // rigid maps: the world-space point is o + t d in any frame
+    return;
+  }
   if (ref_kind(ref) != LEAF_COMPLEX) {
     prim_record(sc, ref, r, t, force_uv, h);
     return;
   }
   Complex cx = sc.complexes[ref_index(ref)];
-  if constexpr (sizeof(R) == 4) {
-    const ComplexXf<R>& xf = sc.complex_xf[ref_index(ref)];
-    RayT<R> lr;
-    lr.time = r.time;
-    if (cx.medium_pos == REF_NONE) {
-      lr.o = xf_point(xf.m_full, xf.b_full, r.o);
-      lr.d = xf_dir(xf.m_full, r.d);
-      prim_record(sc, cx.body, lr, t, force_uv, h);
-      h.normal = xf_dir_transposed(xf.m_full, h.normal);
-    } else {
-      lr.d = xf_dir(xf.m_outer, r.d);
-      h.uv.x = R(0);
-      h.uv.y = R(0);
-      face_normal(lr.d, Vec3<R>(1, 0, 0), h);
-      h.normal = xf_dir_transposed(xf.m_outer, h.normal);
-      h.material = cx.material;
-    }
-    h.object = cx.object;
-    h.p = r.o + t * r.d;  // rigid maps: the world-space point is o + t d in any frame
-    return;
-  }
   RayT<R> lr = r;
   uint32_t n_outer = cx.medium_pos == REF_NONE ? cx.op_count : cx.medium_pos;
   for (uint32_t k = 0; k < n_outer; ++k) {

@@ -114,12 +114,37 @@ RT_DEV R light_pdf_one(const Light<R>& l, Vec3<R> origin, Vec3<R> direction, Cnt
   R solid_angle = R(2) * Consts<R>::pi * (R(1) - cos_theta_max);
   return rrcp(solid_angle);
 }
+// f32 production form of the same test.  For an origin outside the sphere "the probe ray hits
+// it at t >= 0" is "the direction lies inside the tangent cone": cos(angle to the centre) >=
+// cos_theta_max — every quantity of which the pdf needs anyway.  An origin inside (or on) the
+// sphere always hits, and the pdf is the same NaN / inf the reference produces (Q9).
+template <bool STATS>
+RT_DEV float light_pdf_cone(const Light<float>& l, Vec3<float> origin, Vec3<float> unit_direction, Cnt<STATS>& cnt) {
+  if (l.tag != LIGHT_SPHERE) return 0.0f;
+  cnt.template inc<ST_LIGHT_PROBES>();
+  cnt.template inc<ST_SPHERE_TESTS>();
+  const Vec3<float> to_c = Vec3<float>(l.c[0], l.c[1], l.c[2]) - origin;
+  const float d2 = sqrlen(to_c), r2 = l.radius * l.radius;
+  const float cos_theta_max = sqrtf(1.0f - rdiv(r2, d2));
+  const float cos_to_centre = dot(unit_direction, to_c) * __builtin_amdgcn_rsqf(d2);
+  if (!(d2 <= r2 || cos_to_centre >= cos_theta_max)) return 0.0f;
+  cnt.template inc<ST_SPHERE_HITS>();
+  return rrcp(2.0f * Consts<float>::pi * (1.0f - cos_theta_max));
+}
+
 template <typename R, bool STATS>
-RT_DEV R lights_pdf(const SceneView<R>& sc, Vec3<R> origin, Vec3<R> direction, Cnt<STATS>& cnt) {
-  if (sc.lights_kind == LIGHTS_SINGLE) return light_pdf_one(sc.lights[0], origin, direction, cnt);
+RT_DEV R lights_pdf(const SceneView<R>& sc, Vec3<R> origin, Vec3<R> direction, Vec3<R> unit_direction,
+                    Cnt<STATS>& cnt) {
+  auto one = [&](const Light<R>& l) -> R {
+    if constexpr (sizeof(R) == 4)
+      return light_pdf_cone(l, origin, unit_direction, cnt);
+    else
+      return light_pdf_one(l, origin, direction, cnt);
+  };
+  if (sc.lights_kind == LIGHTS_SINGLE) return one(sc.lights[0]);
   R weight = rrcp((R)sc.n_lights);
   R sum = R(0);
-  for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf_one(sc.lights[i], origin, direction, cnt);
+  for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * one(sc.lights[i]);
   return sum;
 }
 
@@ -174,23 +199,54 @@ RT_DEV bool shade(const SceneView<R>& sc, const HitRec<R>& h, RayT<R>& ray, Vec3
   // Lambertian / Isotropic: ScatterRecord::PDF with a cosine PDF (material.rs:59-65, 97-100)
   cnt.template inc<ST_DIFFUSE>();
   Vec3<R> attenuation = texture_value(sc, m.texture, h.uv, h.p, h.normal);
-  ONB<R> uvw = ONB<R>::from_w(h.normal);
   const bool have_lights = sc.lights_kind != LIGHTS_NONE;
-  Vec3<R> direction;
+  // PDF::generate (pdf.rs:33-39): Mixture[light, cosine].choose(), then either
+  // Hittable::random (hittable.rs:502-515) or the cosine direction (alias.rs:72-82).  Both
+  // are "build an ONB on an axis, draw r1 r2, map (z, radial) into it": only the axis and the
+  // z mapping differ, so the two branches share one copy of that code (same arithmetic).
   bool from_light = false;
-  if (have_lights) from_light = rng.below(2) == 0;  // Mixture[light, cosine].choose(), pdf.rs:36
-  if (from_light)
-    direction = lights_random(sc, h.p, rng);
-  else
-    direction = uvw.local(random_cosine_direction<R>(rng));
+  if (have_lights) from_light = rng.below(2) == 0;
+  Vec3<R> axis = h.normal;
+  R light_radius = R(0), distance_squared = R(1);
+  bool no_sample = false;  // a light that is not a Sphere: random() = (1,0,0), no draws
+  if (from_light) {
+    uint32_t i = 0;
+    if (sc.lights_kind == LIGHTS_LIST) i = rng.below(sc.n_lights);  // list.choose()
+    const Light<R> l = sc.lights[i];
+    if (l.tag != LIGHT_SPHERE) {
+      no_sample = true;
+    } else {
+      axis = Vec3<R>(l.c[0], l.c[1], l.c[2]) - h.p;
+      distance_squared = sqrlen(axis);
+      light_radius = l.radius;
+    }
+  }
+  Vec3<R> direction(1, 0, 0);
+  if (!no_sample) {
+    const ONB<R> uvw = ONB<R>::from_w(axis);
+    const R r1 = rng.next<R>();
+    const R r2 = rng.next<R>();
+    R z, radial;
+    if (from_light) {  // alias.rs:84-94
+      z = R(1) + r2 * (rroot(R(1) - rdiv(light_radius * light_radius, distance_squared)) - R(1));
+      radial = rroot(R(1) - z * z);
+    } else {  // alias.rs:72-82
+      z = rroot(R(1) - r2);
+      radial = rroot(r2);
+    }
+    R sn, cs;
+    sincos_2pi(r1, sn, cs);
+    direction = uvw.local(Vec3<R>(cs * radial, sn * radial, z));
+  }
+  const Vec3<R> cos_w = normalize(h.normal);  // = ONB::from_w(hit.normal).w of PDF::Cosine
   // pdf.rs:13-31
   Vec3<R> unit = normalize(direction);
-  R cosine = dot(unit, uvw.w);
+  R cosine = dot(unit, cos_w);
   R cos_pdf = cosine <= R(0) ? R(0) : rdiv(cosine, Consts<R>::pi);
   R pdf_value;
   if (have_lights) {
     pdf_value = R(0);
-    pdf_value += R(0.5) * lights_pdf(sc, h.p, direction, cnt);
+    pdf_value += R(0.5) * lights_pdf(sc, h.p, direction, unit, cnt);
     pdf_value += R(0.5) * cos_pdf;
   } else {
     pdf_value = cos_pdf;
@@ -217,13 +273,22 @@ template <typename R> RT_DEV Vec3<R> primary_direction(const CameraView<R>& cam,
     return cam.lower_left + s * cam.horizontal + t * cam.vertical - cam.origin;
 }
 
-template <typename R> RT_DEV RayT<R> camera_ray(const CameraView<R>& cam, R s, R t, Rng& rng) {  // cam.rs:63-71
+// cam.rs:63-71.  Draw order in slot 0: jitter u, jitter v, shutter time, then the lens-disk
+// rejection pairs (the reference draws the time last; the streams are ours, the quantities are
+// independent).  A pinhole camera (lens_radius == 0) multiplies the disk sample by zero, so its
+// draws are skipped: same ray, one Philox block instead of two or more.
+template <typename R> RT_DEV RayT<R> camera_ray(const CameraView<R>& cam, R s, R t, Rng& rng) {
+  RayT<R> r;
+  r.time = rng.range<R>(cam.time_open, cam.time_close);
+  if (cam.lens_radius == R(0)) {
+    r.o = cam.origin;
+    r.d = primary_direction(cam, s, t);
+    return r;
+  }
   Vec3<R> rd = cam.lens_radius * random_in_unit_disk<R>(rng);
   Vec3<R> offset = cam.u * rd.x + cam.v * rd.y;
-  RayT<R> r;
   r.o = cam.origin + offset;
   r.d = primary_direction(cam, s, t) - offset;
-  r.time = rng.range<R>(cam.time_open, cam.time_close);
   return r;
 }
 
@@ -260,7 +325,7 @@ struct RenderArgs {
   uint64_t seed;
 };
 
-template <typename R, bool STATS, bool EARLY_EXIT>
+template <typename R, bool STATS, bool EARLY_EXIT, bool LINEAR>
 __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
                                                        R* __restrict__ accum, DeviceStats* stats) {
   extern __shared__ uint32_t lds_stack[];
@@ -311,7 +376,10 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
       cnt.template inc<ST_RAYS>();
       R t;
       uint32_t best;
-      traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+      if constexpr (LINEAR)
+        traverse_linear(sc, ray, R(0.001), rng, t, best, cnt);
+      else
+        traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
       bool cont;
       if (best == REF_NONE) {  // main.rs:104
         cnt.template inc<ST_MISSES>();

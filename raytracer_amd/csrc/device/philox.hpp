@@ -22,14 +22,15 @@ RT_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
   const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t h0 = __umulhi(M0, c0), l0 = M0 * c0;
-    uint32_t h1 = __umulhi(M1, c2), l1 = M1 * c2;
-    uint32_t n0 = h1 ^ c1 ^ k0;
-    uint32_t n2 = h0 ^ c3 ^ k1;
+    // one 32x32->64 multiply each (v_mad_u64_u32) instead of a mul_hi + mul_lo pair
+    const uint64_t p0 = (uint64_t)M0 * c0;
+    const uint64_t p1 = (uint64_t)M1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
     c0 = n0;
-    c1 = l1;
+    c1 = (uint32_t)p1;
     c2 = n2;
-    c3 = l0;
+    c3 = (uint32_t)p0;
     k0 += W0;
     k1 += W1;
   }

@@ -97,6 +97,8 @@ template <typename R> struct SceneView {
   const Texture<R>* textures;
   const uint8_t* texels;
   const Light<R>* lights;
+  const uint32_t* linear;  // leaf refs in BVH left-first DFS order (small scenes only)
+  uint32_t n_linear;       // 0 = scene too large for the leaf-list path
   uint32_t root;
   uint32_t lights_kind, n_lights;
   R background[3];

@@ -97,7 +97,9 @@ template <typename R> struct SceneSide {
   SceneView<R> view{};
 };
 
-template <typename R> hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& complexes, SceneSide<R>& s) {
+template <typename R>
+hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& complexes, const std::vector<uint32_t>& linear,
+                      SceneSide<R>& s) {
   std::vector<Node<R>> nodes(d.n_nodes);
   for (uint32_t i = 0; i < d.n_nodes; ++i) {
     std::memset(&nodes[i], 0, sizeof(Node<R>));
@@ -253,7 +255,9 @@ template <typename R> hipError_t build_side(const rt_scene_desc& d, const std::v
   UP(texs, textures)
   UP(texels, texels)
   UP(lights, lights)
+  UP(linear, linear)
 #undef UP
+  s.view.n_linear = (uint32_t)linear.size();
   s.view.root = d.root;
   s.view.lights_kind = d.lights_kind;
   s.view.n_lights = d.n_lights;
@@ -292,7 +296,63 @@ bool is_valid_leaf(uint32_t ref, const rt_scene_desc& d) {
   return RT_REF_KIND(ref) == RT_LEAF_COMPLEX && RT_REF_INDEX(ref) < d.n_complex;
 }
 
+// Conservative world-space bounds of a leaf, or false when they cannot be established here
+// (a moving sphere's extent depends on the ray times the camera will emit).
+bool leaf_world_bounds(const rt_scene_desc& d, const std::vector<Complex>& complexes, uint32_t ref, double lo[3],
+                       double hi[3]) {
+  auto prim_box = [&](uint32_t r, double plo[3], double phi[3]) -> bool {
+    const uint32_t k = RT_REF_KIND(r), i = RT_REF_INDEX(r);
+    if (k == RT_LEAF_SPHERE) {
+      const double* s = d.sphere + 4 * (size_t)i;
+      for (int c = 0; c < 3; ++c) {
+        plo[c] = s[c] - std::fabs(s[3]);
+        phi[c] = s[c] + std::fabs(s[3]);
+      }
+      return true;
+    }
+    if (k == RT_LEAF_CUBE) {
+      const double* q = d.cube + 6 * (size_t)i;
+      for (int c = 0; c < 3; ++c) {
+        plo[c] = std::fmin(q[c], q[3 + c]);
+        phi[c] = std::fmax(q[c], q[3 + c]);
+      }
+      return true;
+    }
+    return false;
+  };
+  if (RT_REF_KIND(ref) != RT_LEAF_COMPLEX) return prim_box(ref, lo, hi);
+  const Complex& cx = complexes[RT_REF_INDEX(ref)];
+  double plo[3], phi[3];
+  if (!prim_box(cx.body, plo, phi)) return false;
+  for (int c = 0; c < 3; ++c) {
+    lo[c] = INFINITY;
+    hi[c] = -INFINITY;
+  }
+  for (int corner = 0; corner < 8; ++corner) {
+    double p[3] = {(corner & 1) ? phi[0] : plo[0], (corner & 2) ? phi[1] : plo[1], (corner & 4) ? phi[2] : plo[2]};
+    // undo the wrappers innermost first: Rotate by q* (hittable.rs:379-383), Translate by +offset
+    for (uint32_t k = cx.op_count; k-- > 0;) {
+      const uint32_t o = cx.op_first + k;
+      const double* q = d.op_data + 4 * (size_t)o;
+      if (d.op_tag[o] == RT_OP_TRANSLATE) {
+        for (int c = 0; c < 3; ++c) p[c] += q[c];
+      } else if (d.op_tag[o] == RT_OP_ROTATE) {
+        const double qi[4] = {q[0], -q[1], -q[2], -q[3]};
+        double r[3];
+        host_qrotate(p, qi, r);
+        for (int c = 0; c < 3; ++c) p[c] = r[c];
+      }
+    }
+    for (int c = 0; c < 3; ++c) {
+      lo[c] = std::fmin(lo[c], p[c]);
+      hi[c] = std::fmax(hi[c], p[c]);
+    }
+  }
+  return true;
+}
+
 constexpr uint32_t MAX_STACK_DEPTH = 64;
+constexpr uint32_t MAX_LINEAR_LEAVES = 16;  // scenes up to this many leaves take the leaf-list path (f32)
 constexpr uint32_t TARGET_WAVES = 256u * 16u;  // enough waves to fill 256 CUs at 4 waves/SIMD
 
 }  // namespace
@@ -439,12 +499,50 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
   if (device < 0 || device >= ndev) return fail(RT_ERR_BAD_ARG, "rt_scene_create: device %d of %d", device, ndev);
   HIP_TRY(hipSetDevice(device));
 
+  // Leaves in left-first DFS order (the order the reference's recursion reaches them), for the
+  // leaf-list path.  That path is only equivalent to the BVH walk when every node box really
+  // bounds the leaves below it; the reference's Rotate::bounding_box does not (it can
+  // clip the object), and then pruning is part of the result.  So: verify containment, and fall
+  // back to the BVH walk for any scene where a box is not conservative (or cannot be checked).
+  std::vector<uint32_t> linear;
+  if (d->root != RT_REF_NONE) {
+    struct Todo {
+      uint32_t ref, depth;
+    };
+    std::vector<Todo> todo{{d->root, 0}};
+    std::vector<uint32_t> path;  // node indices from the root to the current position
+    bool ok = true;
+    while (!todo.empty() && ok) {
+      Todo cur = todo.back();
+      todo.pop_back();
+      path.resize(cur.depth);
+      if (!(cur.ref & RT_REF_LEAF)) {
+        path.push_back(cur.ref);
+        todo.push_back({d->node_right[cur.ref], cur.depth + 1});
+        todo.push_back({d->node_left[cur.ref], cur.depth + 1});
+        continue;
+      }
+      linear.push_back(cur.ref);
+      if (linear.size() > MAX_LINEAR_LEAVES) ok = false;
+      double lo[3], hi[3];
+      if (ok && !leaf_world_bounds(*d, complexes, cur.ref, lo, hi)) ok = false;
+      for (size_t a = 0; ok && a < path.size(); ++a) {
+        const double* nb = d->node_box + 6 * (size_t)path[a];
+        for (int k = 0; k < 3; ++k) {
+          const double tol = 1e-9 * (1.0 + std::fabs(lo[k]) + std::fabs(hi[k]));
+          if (!(nb[k] <= lo[k] + tol && hi[k] <= nb[3 + k] + tol)) ok = false;
+        }
+      }
+    }
+    if (!ok) linear.clear();
+  }
+
   rt_scene* s = new rt_scene;
   s->device = device;
   s->stack_depth = std::max(tree_height, 1u);
   hipError_t e;
-  if ((e = build_side<float>(*d, complexes, s->f32)) != hipSuccess ||
-      (e = build_side<double>(*d, complexes, s->f64)) != hipSuccess ||
+  if ((e = build_side<float>(*d, complexes, linear, s->f32)) != hipSuccess ||
+      (e = build_side<double>(*d, complexes, linear, s->f64)) != hipSuccess ||
       (e = hipMalloc((void**)&s->dstats, sizeof(DeviceStats))) != hipSuccess ||
       (e = hipEventCreate(&s->ev0)) != hipSuccess || (e = hipEventCreate(&s->ev1)) != hipSuccess) {
     delete s;
@@ -471,8 +569,9 @@ int check_camera(const rt_camera* cam) {
   return RT_OK;
 }
 
-LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_samples) {
+LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_samples, bool allow_linear = false) {
   LaunchShape sh;
+  sh.linear = allow_linear && s->f32.view.n_linear > 0;
   uint32_t tx = (w + 15) / 16, ty = (h + 15) / 16;
   sh.tiles = tx * ty;
   sh.stack_depth = s->stack_depth;
@@ -553,7 +652,7 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
   if (p->spp == 0 && !accumulate) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
   while (done < p->spp) {
     uint32_t n = std::min(per_launch, p->spp - done);
-    LaunchShape sh = make_shape(s, p->width, p->height, n);
+    LaunchShape sh = make_shape(s, p->width, p->height, n, sizeof(R) == 4 && !(p->flags & RT_FLAG_FORCE_BVH));
     int acc = (accumulate || !first) ? 1 : 0;
     if (sh.splits > 1 && !acc) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
     HIP_TRY(Side<R>::render(sv, cv, p->width, p->height, (uint32_t)(p->sample_offset + done), n, p->max_depth, p->seed,

@@ -1,6 +1,7 @@
 // Production precision: f32 kernels for gfx950 (fp contraction on).
 #define RT_SUFFIX f32
 #define RT_REAL float
+#define RT_HAS_LINEAR 1
 #define RT_EARLY_EXIT true
 #define RT_DEFINE_COMMON 1
 #include "launch_impl.hpp"

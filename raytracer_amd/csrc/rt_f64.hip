@@ -2,5 +2,6 @@
 // draw-for-draw and branch-for-branch comparable with the CPU oracle.  Not a production path.
 #define RT_SUFFIX f64
 #define RT_REAL double
+#define RT_HAS_LINEAR 0
 #define RT_EARLY_EXIT false
 #include "launch_impl.hpp"

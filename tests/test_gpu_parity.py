@@ -113,3 +113,26 @@ def test_render_f32_within_monte_carlo_noise(name, earthmap):
           f"nonfinite samples {gst['nonfinite_samples']}")
     assert d_gpu <= 1.25 * d_ref + 1e-4
     assert abs(mean_ratio - 1.0) <= 0.02
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "small_scene", "two_spheres", "cube_scene"])
+def test_leaf_list_path_equals_bvh_walk(name, earthmap):
+    """Small scenes take the leaf-list traversal in f32; RT_FLAG_FORCE_BVH walks the BVH instead.
+    Same leaves in the same order with the same bounds: same winners, same draws, same image."""
+    hs, ds, os_, h, depth = _pair(name, earthmap)
+    a, sa = ds.render(W, h, 32, depth, seed=5, stats=True)
+    b, sb = ds.render(W, h, 32, depth, seed=5, stats=True, force_bvh=True)
+    assert sa["rays"] == sb["rays"]
+    for k in ("closest_hits", "diffuse_vertices", "specular_vertices", "emitter_hits", "misses"):
+        assert sa[k] == sb[k], (k, sa[k], sb[k])
+    if hs.desc.n_nodes:
+        assert sa["nodes_visited"] == 0 and sb["nodes_visited"] > 0
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_leaf_list_path_refused_when_boxes_clip(earthmap):
+    """simple_light is built with the reference's Rotate::bounding_box (Q3), whose box does not bound
+    the rotated cube: BVH pruning is then part of the image, so the library must walk the BVH."""
+    hs, ds, os_, h, depth = _pair("simple_light", earthmap)
+    a, sa = ds.render(W, h, 4, depth, seed=5, stats=True)
+    assert sa["nodes_visited"] > 0
