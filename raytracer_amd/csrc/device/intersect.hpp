@@ -281,7 +281,11 @@ RT_DEV void traverse_linear(const SceneView<R>& sc, const RayT<R>& r, R t_min, R
   best = REF_NONE;
   const Vec3<R> inv_d = inverse3(r.d);
   const R a = sqrlen(r.d);
+#ifdef RT_ABL_TRAV1
+  for (uint32_t k = 2; k < 3; ++k) {
+#else
   for (uint32_t k = 0; k < sc.n_linear; ++k) {
+#endif
     const uint32_t cur = sc.linear[k];
     R t;
     bool h;

@@ -315,6 +315,24 @@ RT_DEV void tile_pixel(uint32_t width, uint32_t& px, uint32_t& py) {
   py = (tile / tiles_x) * 16u + (wave >> 1) * 8u + (lane >> 3);
 }
 
+// Diagnostic build (-DRT_STAMPS): s_memtime stamps at wave-convergent points of the bounce loop;
+// the per-phase wave-cycle sums leave the kernel only through DeviceStats::stamp.
+#ifdef RT_STAMPS
+#define RT_STAMP(i)                                                                    \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    unsigned long long now_;                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");       \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    stamp_acc[i] += now_ - stamp_last;                                                 \
+    stamp_last = now_;                                                                 \
+  } while (0)
+#else
+#define RT_STAMP(i) \
+  do {              \
+  } while (0)
+#endif
+
 struct RenderArgs {
   uint32_t width, height;
   uint32_t sample_begin;  // global index of this launch's first sample
@@ -351,7 +369,12 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
     uint32_t depth_left = 0, slot = 0;
     Rng rng;
     rng.init(a.seed, pixel, 0);
+#ifdef RT_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     for (;;) {
+      RT_STAMP(0);
       if (!alive) {
         if (s == s_end) break;
         rng.sample = a.sample_begin + s;
@@ -372,14 +395,17 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
           continue;
         }
       }
+      RT_STAMP(1);
       rng.begin(slot);
       cnt.template inc<ST_RAYS>();
+      RT_STAMP(2);
       R t;
       uint32_t best;
       if constexpr (LINEAR)
         traverse_linear(sc, ray, R(0.001), rng, t, best, cnt);
       else
         traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+      RT_STAMP(3);
       bool cont;
       if (best == REF_NONE) {  // main.rs:104
         cnt.template inc<ST_MISSES>();
@@ -389,8 +415,15 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
         cnt.template inc<ST_CLOSEST>();
         HitRec<R> h;
         make_hit_record(sc, best, ray, t, false, h);
+        RT_STAMP(4);
+#ifdef RT_ABL_NOSHADE
+        L = L + thr * h.normal;
+        cont = false;
+#else
         cont = shade(sc, h, ray, thr, L, rng, cnt);
+#endif
       }
+      RT_STAMP(5);
       ++slot;
       --depth_left;
       if (depth_left == 0) cont = false;  // the next ray_color call would return 0
@@ -404,6 +437,10 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
         alive = false;
       }
     }
+#ifdef RT_STAMPS
+    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)))
+      for (int i = 0; i < 8; ++i) atomicAdd(&stats->stamp[i], stamp_acc[i]);
+#endif
     R* out = accum + 3ull * pixel;
     if (a.splits > 1) {
       atomicAdd(out + 0, acc.x);

@@ -21,7 +21,10 @@ RT_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
   const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+#ifndef RT_PHILOX_ROUNDS
+#define RT_PHILOX_ROUNDS 10
+#endif
+  for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
     // one 32x32->64 multiply each (v_mad_u64_u32) instead of a mul_hi + mul_lo pair
     const uint64_t p0 = (uint64_t)M0 * c0;
     const uint64_t p1 = (uint64_t)M1 * c2;

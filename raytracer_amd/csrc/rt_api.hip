@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -668,6 +669,11 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
     HIP_TRY(hipStreamSynchronize(stream));
     std::memset(stats, 0, sizeof(*stats));
     stats_to_abi(hs, stats);
+    if (getenv("RT_PRINT_STAMPS")) {
+      fprintf(stderr, "stamps:");
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", hs.stamp[i]);
+      fprintf(stderr, "\n");
+    }
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     stats->kernel_ms = ms;

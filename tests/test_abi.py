@@ -1,0 +1,123 @@
+"""The C-ABI libraries load without a GPU and export every symbol the headers declare; argument
+validation works without touching a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, prefix):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s[a-z0-9_]+)\s*\(" % prefix, src)))
+
+
+def test_librt_hip_exports_every_declared_symbol():
+    from raytracer_amd import _ffi as F
+    names = _declared("rt.h", "rt_")
+    assert sorted(names) == sorted(F.RT_SYMBOLS)
+    for n in names:
+        assert hasattr(F.hip, n), n
+
+
+def test_librt_host_exports_every_declared_symbol():
+    from raytracer_amd import _ffi as F
+    names = _declared("rt_host.h", "rth_")
+    assert sorted(names) == sorted(F.RTH_SYMBOLS)
+    for n in names:
+        assert hasattr(F.host, n), n
+
+
+def test_abi_version_and_struct_layout():
+    from raytracer_amd import _ffi as F
+    assert F.hip.rt_abi_version() == F.RT_ABI_VERSION
+    # the ctypes mirror must have the C layout: rth_scene_desc() hands back a C struct
+    import raytracer_amd as R
+    hs = R.HostScene("cornell_box", 1.0)
+    d = hs.desc
+    assert d.abi_version == F.RT_ABI_VERSION
+    assert d.n_cubes == 7 and d.n_spheres == 1 and d.n_complex == 2 and d.n_ops == 4
+    assert d.n_nodes == 7 and d.bvh_height == 3 and d.lights_kind == 1 and d.n_lights == 1
+    assert list(d.background) == [0.0, 0.0, 0.0]
+    assert [d.light_sphere[i] for i in range(4)] == [278.0, 480.0, 278.0, 60.0]
+    assert C.sizeof(F.RtCamera) == 21 * 8 and C.sizeof(F.RtParams) == 40
+
+
+def test_scene_create_validates_before_touching_the_device():
+    """Bad descriptions are refused with RT_ERR_BAD_ARG / RT_ERR_UNSUPPORTED and a message (the
+    reference would panic).  Validation runs before any HIP call, so this needs no GPU."""
+    from raytracer_amd import _ffi as F
+    import raytracer_amd as R
+    hs = R.HostScene("cornell_box", 1.0)
+    out = C.c_void_p()
+
+    def attempt(mutate):
+        d = F.RtSceneDesc()
+        C.memmove(C.byref(d), C.byref(hs.desc), C.sizeof(d))
+        keep = mutate(d)
+        rc = F.hip.rt_scene_create(0, C.byref(d), C.byref(out))
+        return rc, F.hip.rt_last_error().decode(), keep
+
+    rc, msg, _ = attempt(lambda d: setattr(d, "abi_version", 99))
+    assert rc == F.RT_ERR_BAD_ARG and "abi_version" in msg
+    rc, msg, _ = attempt(lambda d: setattr(d, "root", 1000))
+    assert rc == F.RT_ERR_BAD_ARG and "root" in msg
+    rc, msg, _ = attempt(lambda d: setattr(d, "lights_kind", 0))
+    assert rc == F.RT_ERR_BAD_ARG and "lights" in msg
+
+    def cyclic(d):  # a child that points backwards would make traversal loop forever
+        left = np.ctypeslib.as_array(d.node_left, shape=(d.n_nodes,)).copy()
+        left[3] = 0
+        d.node_left = left.ctypes.data_as(C.POINTER(C.c_uint32))
+        return left
+    rc, msg, _ = attempt(cyclic)
+    assert rc == F.RT_ERR_BAD_ARG and "pre-order" in msg
+
+    def bad_material(d):
+        m = np.ctypeslib.as_array(d.cube_material, shape=(d.n_cubes,)).copy()
+        m[0] = 10**6
+        d.cube_material = m.ctypes.data_as(C.POINTER(C.c_uint32))
+        return m
+    rc, msg, _ = attempt(bad_material)
+    assert rc == F.RT_ERR_BAD_ARG and "material" in msg
+
+    def non_unit_quaternion(d):
+        q = np.ctypeslib.as_array(d.op_data, shape=(d.n_ops * 4,)).copy()
+        tags = np.ctypeslib.as_array(d.op_tag, shape=(d.n_ops,))
+        k = int(np.nonzero(tags == 1)[0][0])
+        q[4 * k: 4 * k + 4] *= 2.0
+        d.op_data = q.ctypes.data_as(C.POINTER(C.c_double))
+        return q
+    rc, msg, _ = attempt(non_unit_quaternion)
+    assert rc == F.RT_ERR_UNSUPPORTED and "quaternion" in msg
+
+    assert F.hip.rt_scene_create(0, None, C.byref(out)) == F.RT_ERR_BAD_ARG
+
+
+def test_host_errors_are_reported_not_thrown():
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    o = F.RthSceneOpts()
+    o.scene_id, o.rotate_bbox, o.aspect_ratio, o.scene_seed, o.bvh_seed = 2, -1, 1.5, 5, 7  # earth, no texels
+    h = C.c_void_p()
+    rc = F.host.rth_scene_build(C.byref(o), C.byref(h))
+    assert rc == F.RT_ERR_BAD_ARG and b"texels" in F.host.rth_last_error()
+
+
+def test_tonemap_matches_reference_formula():
+    """main.rs:51-63 + 167: mean, sqrt, clamp(0, 0.9999), *256, truncate; NaN -> 0; inf -> 255."""
+    import raytracer_amd as R
+    import oracle_ffi as O
+    spp = 7
+    vals = np.array([0.0, 1e-6, 0.25, 0.5, 0.999, 1.0, 4.0, -1.0, np.nan, np.inf, 0.7, 0.1], dtype=np.float64)
+    acc = (vals * spp).reshape(2, 2, 3)
+    got = R.tonemap(acc.astype(np.float32), spp)
+    want = O.tonemap(acc, spp)
+    assert np.array_equal(got, want)
+    g = np.sqrt(vals[:7])
+    assert list(got.reshape(-1)[:7]) == [int(min(max(x, 0), 0.9999) * 256) for x in g]
+    assert list(got.reshape(-1)[7:10]) == [0, 0, 255]
