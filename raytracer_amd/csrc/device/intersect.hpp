@@ -271,31 +271,79 @@ RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng
 // same shrinking t_max and the same strict `<` — exactly the reference's List arm
 // (hittable.rs:387-399).  A leaf that the BVH would have pruned can only be hit outside
 // (t_min, closest), which its own test rejects (and a medium returns before drawing), so the
-// winner and the draw sequence equal the BVH walk's.  The loop counter is wave-uniform: every
-// lane tests the same leaf at the same time (no traversal divergence) and the compiler fetches
-// leaf data through the scalar cache.
-template <typename R, bool STATS>
-RT_DEV void traverse_linear(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, R& closest,
-                            uint32_t& best, Cnt<STATS>& cnt) {
-  closest = Consts<R>::inf;
-  best = REF_NONE;
-  const Vec3<R> inv_d = inverse3(r.d);
-  const R a = sqrlen(r.d);
-#ifdef RT_ABL_TRAV1
-  for (uint32_t k = 2; k < 3; ++k) {
-#else
-  for (uint32_t k = 0; k < sc.n_linear; ++k) {
-#endif
-    const uint32_t cur = sc.linear[k];
-    R t;
+// winner and the draw sequence equal the BVH walk's (rt_scene_create verifies that every node
+// box really bounds its leaves before enabling this path).  The loop counter is wave-uniform:
+// every lane tests the same leaf at the same time (no traversal divergence), and the leaf
+// records sit in LDS in a fixed layout (no dependent loads).
+template <bool STATS>
+RT_DEV bool lin_prim_t(const float* rec, uint32_t flags, Vec3<float> o, Vec3<float> d, Vec3<float> inv_d, float a,
+                       float t_min, float t_max, float& t_out, Cnt<STATS>& cnt) {
+  if (flags & LINF_CUBE) {
+    cnt.template inc<ST_CUBE_TESTS>();
+    float lo = t_min, hi = t_max;
+    if (!slab_hit(rec + LIN_PRIM, rec + LIN_PRIM + 3, o, inv_d, lo, hi)) return false;
+    cnt.template inc<ST_CUBE_HITS>();
+    t_out = lo;
+    return true;
+  }
+  cnt.template inc<ST_SPHERE_TESTS>();
+  const bool h = sphere_t(o, d, a, Vec3<float>(rec[LIN_PRIM], rec[LIN_PRIM + 1], rec[LIN_PRIM + 2]), rec[LIN_PRIM + 3],
+                          t_min, t_max, t_out);
+  if (h) cnt.template inc<ST_SPHERE_HITS>();
+  return h;
+}
+
+template <bool STATS>
+RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, const RayT<float>& r, float t_min, Rng& rng,
+                            float& closest, uint32_t& best_k, Cnt<STATS>& cnt) {
+  closest = Consts<float>::inf;
+  best_k = REF_NONE;
+  const Vec3<float> inv_d0 = inverse3(r.d);
+  const float a0 = sqrlen(r.d);
+  for (uint32_t k = 0; k < n_linear; ++k) {
+    const float* rec = lin + k * LIN_DWORDS;
+    const uint32_t flags = __float_as_uint(rec[LIN_FLAGS]);
+    Vec3<float> o = r.o, d = r.d, inv_d = inv_d0;
+    float a = a0;
+    if (flags & LINF_XF) {  // wave-uniform branch
+      o = xf_point(rec + LIN_M, rec + LIN_B, r.o);
+      d = xf_dir(rec + LIN_M, r.d);
+      inv_d = inverse3(d);
+      a = sqrlen(d);
+      if constexpr (STATS) {
+        cnt.template inc<ST_ROTATE>(__float_as_uint(rec[LIN_FLAGS]) >> 16 & 0xFF);
+        cnt.template inc<ST_TRANSLATE>(__float_as_uint(rec[LIN_FLAGS]) >> 24);
+      }
+    }
+    float t;
     bool h;
-    if (ref_kind(cur) == LEAF_COMPLEX)
-      h = complex_t(sc, ref_index(cur), r, t_min, closest, rng, t, cnt);
-    else
-      h = prim_t(sc, cur, r, inv_d, a, t_min, closest, t, cnt);
+    if (!(flags & LINF_MEDIUM)) {
+      h = lin_prim_t(rec, flags, o, d, inv_d, a, t_min, closest, t, cnt);
+    } else {  // hittable.rs:319-349
+      cnt.template inc<ST_MEDIUM>();
+      h = false;
+      float t1, t2;
+      cnt.template inc<ST_MEDIUM_PROBES>();
+      if (lin_prim_t(rec, flags, o, d, inv_d, a, -Consts<float>::inf, Consts<float>::inf, t1, cnt)) {
+        cnt.template inc<ST_MEDIUM_PROBES>();
+        if (lin_prim_t(rec, flags, o, d, inv_d, a, t1 + 0.0001f, Consts<float>::inf, t2, cnt)) {
+          t1 = rmax(t1, t_min);
+          t2 = rmin(t2, closest);
+          if (t1 < t2) {
+            t1 = rmax(t1, 0.0f);
+            const float ray_length = length(r.d);  // rigid maps keep |d|
+            const float hit_distance = rec[LIN_NID] * rlog(rng.next<float>());
+            if (!(hit_distance > (t2 - t1) * ray_length)) {
+              t = t1 + rdiv(hit_distance, ray_length);
+              h = true;
+            }
+          }
+        }
+      }
+    }
     if (h && t < closest) {
       closest = t;
-      best = cur;
+      best_k = k;
     }
   }
 }
@@ -314,6 +362,19 @@ RT_DEV void face_normal(Vec3<R> d, Vec3<R> outward, HitRec<R>& h) {  // hittable
   h.normal = h.front_face ? outward : -outward;
 }
 
+// hittable.rs:233-249: the "outward" normal by which face rel_p lies within epsilon of (Q1: it
+// points inward), else the (0.5,0.5,0.5) fallback (Q2)
+template <typename R> RT_DEV Vec3<R> cube_normal(Vec3<R> rel) {
+  const R eps = R(0.002);
+  if (rel.x < eps) return Vec3<R>(1, 0, 0);
+  if (rel.x > R(1) - eps) return Vec3<R>(-1, 0, 0);
+  if (rel.y < eps) return Vec3<R>(0, 1, 0);
+  if (rel.y > R(1) - eps) return Vec3<R>(0, -1, 0);
+  if (rel.z < eps) return Vec3<R>(0, 0, 1);
+  if (rel.z > R(1) - eps) return Vec3<R>(0, 0, -1);
+  return normalize(Vec3<R>(R(0.5), R(0.5), R(0.5)));
+}
+
 template <typename R>
 RT_DEV void prim_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, R t, bool force_uv, HitRec<R>& h) {
   uint32_t kind = ref_kind(ref), idx = ref_index(ref);
@@ -325,22 +386,7 @@ RT_DEV void prim_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, 
     h.object = at.object;
     Vec3<R> p0(c.p0[0], c.p0[1], c.p0[2]), p1(c.p1[0], c.p1[1], c.p1[2]);
     Vec3<R> rel = (h.p - p0) / (p1 - p0);
-    const R eps = R(0.002);
-    Vec3<R> n;
-    if (rel.x < eps)
-      n = Vec3<R>(1, 0, 0);
-    else if (rel.x > R(1) - eps)
-      n = Vec3<R>(-1, 0, 0);
-    else if (rel.y < eps)
-      n = Vec3<R>(0, 1, 0);
-    else if (rel.y > R(1) - eps)
-      n = Vec3<R>(0, -1, 0);
-    else if (rel.z < eps)
-      n = Vec3<R>(0, 0, 1);
-    else if (rel.z > R(1) - eps)
-      n = Vec3<R>(0, 0, -1);
-    else
-      n = normalize(Vec3<R>(R(0.5), R(0.5), R(0.5)));
+    Vec3<R> n = cube_normal(rel);
     R az = rabs(n.z), ax = rabs(n.x), ay = rabs(n.y);
     h.uv.x = rel.x * az + rel.y * ax + rel.x * ay;
     h.uv.y = rel.y * az + rel.z * ax + rel.z * ay;
@@ -452,6 +498,49 @@ RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>&
       h.normal = qrotate(h.normal, qi);
     }
   }
+}
+
+// HitRecord + material of the winning leaf from its LDS record (f32 leaf-list path).
+RT_DEV void lin_hit_record(const SceneView<float>& sc, const float* rec, const RayT<float>& r, float t, HitRec<float>& h,
+                           Material<float>& mat) {
+  const uint32_t flags = __float_as_uint(rec[LIN_FLAGS]);
+  Vec3<float> o = r.o, d = r.d;
+  if (flags & LINF_XF) {
+    o = xf_point(rec + LIN_M, rec + LIN_B, r.o);
+    d = xf_dir(rec + LIN_M, r.d);
+  }
+  mat.tag = __float_as_uint(rec[LIN_MAT + 0]);
+  mat.texture = __float_as_uint(rec[LIN_MAT + 1]);
+  mat.flags = __float_as_uint(rec[LIN_MAT + 2]);
+  mat.pad = 0;
+  for (int i = 0; i < 4; ++i) mat.p[i] = rec[LIN_MAT + 4 + i];
+  for (int i = 0; i < 3; ++i) mat.color[i] = rec[LIN_MAT + 8 + i];
+  h.material = REF_NONE;
+  h.object = __float_as_uint(rec[LIN_OBJECT]);
+  h.uv.x = 0.0f;
+  h.uv.y = 0.0f;
+  if (flags & LINF_MEDIUM) {  // hittable.rs:349-362 (the medium op is outermost in this path's records)
+    face_normal(r.d, Vec3<float>(1, 0, 0), h);
+  } else if (flags & LINF_CUBE) {
+    const Vec3<float> pl = o + t * d;
+    const Vec3<float> p0(rec[LIN_PRIM], rec[LIN_PRIM + 1], rec[LIN_PRIM + 2]);
+    const Vec3<float> p1(rec[LIN_PRIM + 3], rec[LIN_PRIM + 4], rec[LIN_PRIM + 5]);
+    const Vec3<float> rel = (pl - p0) / (p1 - p0);
+    const Vec3<float> n = cube_normal(rel);
+    const float az = rabs(n.z), ax = rabs(n.x), ay = rabs(n.y);
+    h.uv.x = rel.x * az + rel.y * ax + rel.x * ay;
+    h.uv.y = rel.y * az + rel.z * ax + rel.z * ay;
+    face_normal(d, n, h);
+  } else {
+    const Vec3<float> pl = o + t * d;
+    const Vec3<float> c(rec[LIN_PRIM], rec[LIN_PRIM + 1], rec[LIN_PRIM + 2]);
+    const Vec3<float> outward = sphere_outward(o, d, t, pl, c, rec[LIN_PRIM + 3]);
+    if (mat.flags & MATF_NEEDS_UV) h.uv = get_sphere_uv(outward);
+    face_normal(d, outward, h);
+  }
+  if ((flags & LINF_XF) && !(flags & LINF_MEDIUM)) h.normal = xf_dir_transposed(rec + LIN_M, h.normal);
+  h.p = r.o + t * r.d;
+  (void)sc;
 }
 
 }  // namespace rt

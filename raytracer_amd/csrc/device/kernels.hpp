@@ -88,19 +88,7 @@ template <typename R> RT_DEV Vec3<R> random_to_sphere(Rng& rng, R radius, R dist
   return Vec3<R>(x, y, z);
 }
 
-// ---- hittable.rs:477-515 on the flattened light list ----------------------------------------
-template <typename R> RT_DEV Vec3<R> light_random_one(const Light<R>& l, Vec3<R> origin, Rng& rng) {
-  if (l.tag != LIGHT_SPHERE) return Vec3<R>(1, 0, 0);
-  Vec3<R> direction = Vec3<R>(l.c[0], l.c[1], l.c[2]) - origin;
-  R distance_squared = sqrlen(direction);
-  ONB<R> uvw = ONB<R>::from_w(direction);
-  return uvw.local(random_to_sphere<R>(rng, l.radius, distance_squared));
-}
-template <typename R> RT_DEV Vec3<R> lights_random(const SceneView<R>& sc, Vec3<R> origin, Rng& rng) {
-  uint32_t i = 0;
-  if (sc.lights_kind == LIGHTS_LIST) i = rng.below(sc.n_lights);  // list.choose()
-  return light_random_one(sc.lights[i], origin, rng);
-}
+// ---- hittable.rs:477-500 on the flattened light list (random(): see shade()) -------------------
 template <typename R, bool STATS>
 RT_DEV R light_pdf_one(const Light<R>& l, Vec3<R> origin, Vec3<R> direction, Cnt<STATS>& cnt) {
   if (l.tag != LIGHT_SPHERE) return R(0);
@@ -133,19 +121,25 @@ RT_DEV float light_pdf_cone(const Light<float>& l, Vec3<float> origin, Vec3<floa
 }
 
 template <typename R, bool STATS>
-RT_DEV R lights_pdf(const SceneView<R>& sc, Vec3<R> origin, Vec3<R> direction, Vec3<R> unit_direction,
-                    Cnt<STATS>& cnt) {
+RT_DEV R lights_pdf(const SceneView<R>& sc, const Light<R>* lights, Vec3<R> origin, Vec3<R> direction,
+                    Vec3<R> unit_direction, Cnt<STATS>& cnt) {
   auto one = [&](const Light<R>& l) -> R {
     if constexpr (sizeof(R) == 4)
       return light_pdf_cone(l, origin, unit_direction, cnt);
     else
       return light_pdf_one(l, origin, direction, cnt);
   };
-  if (sc.lights_kind == LIGHTS_SINGLE) return one(sc.lights[0]);
+  if (sc.lights_kind == LIGHTS_SINGLE) return one(lights[0]);
   R weight = rrcp((R)sc.n_lights);
   R sum = R(0);
-  for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * one(sc.lights[i]);
+  for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * one(lights[i]);
   return sum;
+}
+
+// texture.value() of a material's texture; Solid textures were folded into the material record
+template <typename R> RT_DEV Vec3<R> material_color(const SceneView<R>& sc, const Material<R>& m, const HitRec<R>& h) {
+  if (m.flags & MATF_SOLID) return Vec3<R>(m.color[0], m.color[1], m.color[2]);
+  return texture_value(sc, m.texture, h.uv, h.p, h.normal);
 }
 
 // material.rs:128-133
@@ -162,12 +156,11 @@ template <typename R> RT_DEV R reflectance(R cosine, R ref_idx) {
 // running throughput / radiance, overwrites `ray` with the scattered ray and returns true if
 // the path continues.
 template <typename R, bool STATS>
-RT_DEV bool shade(const SceneView<R>& sc, const HitRec<R>& h, RayT<R>& ray, Vec3<R>& thr, Vec3<R>& L, Rng& rng,
-                  Cnt<STATS>& cnt) {
-  Material<R> m = sc.materials[h.material];
+RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material<R>& m, const HitRec<R>& h,
+                  RayT<R>& ray, Vec3<R>& thr, Vec3<R>& L, Rng& rng, Cnt<STATS>& cnt) {
   if (m.tag == MAT_DIFFUSE_LIGHT) {  // scatter -> None: return emitted (main.rs:101)
     cnt.template inc<ST_EMITTER>();
-    if (h.front_face) L = L + thr * texture_value(sc, m.texture, h.uv, h.p, h.normal);
+    if (h.front_face) L = L + thr * material_color(sc, m, h);
     return false;
   }
   if (m.tag == MAT_DIELECTRIC) {  // material.rs:66-87; emitted is dropped (main.rs:81-83)
@@ -198,7 +191,7 @@ RT_DEV bool shade(const SceneView<R>& sc, const HitRec<R>& h, RayT<R>& ray, Vec3
   }
   // Lambertian / Isotropic: ScatterRecord::PDF with a cosine PDF (material.rs:59-65, 97-100)
   cnt.template inc<ST_DIFFUSE>();
-  Vec3<R> attenuation = texture_value(sc, m.texture, h.uv, h.p, h.normal);
+  Vec3<R> attenuation = material_color(sc, m, h);
   const bool have_lights = sc.lights_kind != LIGHTS_NONE;
   // PDF::generate (pdf.rs:33-39): Mixture[light, cosine].choose(), then either
   // Hittable::random (hittable.rs:502-515) or the cosine direction (alias.rs:72-82).  Both
@@ -212,7 +205,7 @@ RT_DEV bool shade(const SceneView<R>& sc, const HitRec<R>& h, RayT<R>& ray, Vec3
   if (from_light) {
     uint32_t i = 0;
     if (sc.lights_kind == LIGHTS_LIST) i = rng.below(sc.n_lights);  // list.choose()
-    const Light<R> l = sc.lights[i];
+    const Light<R> l = lights[i];
     if (l.tag != LIGHT_SPHERE) {
       no_sample = true;
     } else {
@@ -246,7 +239,7 @@ RT_DEV bool shade(const SceneView<R>& sc, const HitRec<R>& h, RayT<R>& ray, Vec3
   R pdf_value;
   if (have_lights) {
     pdf_value = R(0);
-    pdf_value += R(0.5) * lights_pdf(sc, h.p, direction, unit, cnt);
+    pdf_value += R(0.5) * lights_pdf(sc, lights, h.p, direction, unit, cnt);
     pdf_value += R(0.5) * cos_pdf;
   } else {
     pdf_value = cos_pdf;
@@ -348,6 +341,21 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
                                                        R* __restrict__ accum, DeviceStats* stats) {
   extern __shared__ uint32_t lds_stack[];
   uint32_t* stack = lds_stack + threadIdx.x;
+  // small read-mostly tables staged in LDS once per workgroup: the lights, and (leaf-list path)
+  // the fixed-layout leaf records
+  __shared__ Light<R> s_lights[LDS_MAX_LIGHTS];
+  __shared__ float s_lin[LINEAR ? LIN_MAX_LEAVES * LIN_DWORDS : 1];
+  {
+    const uint32_t n_l = sc.n_lights < LDS_MAX_LIGHTS ? sc.n_lights : LDS_MAX_LIGHTS;
+    constexpr uint32_t LW = sizeof(Light<R>) / 4;
+    for (uint32_t i = threadIdx.x; i < n_l * LW; i += BLOCK)
+      reinterpret_cast<uint32_t*>(s_lights)[i] = reinterpret_cast<const uint32_t*>(sc.lights)[i];
+    if constexpr (LINEAR)
+      for (uint32_t i = threadIdx.x; i < sc.n_linear * LIN_DWORDS; i += BLOCK)
+        s_lin[i] = __uint_as_float(sc.linear_rec[i]);
+    __syncthreads();
+  }
+  const Light<R>* lights = sc.n_lights <= LDS_MAX_LIGHTS ? s_lights : sc.lights;
   uint32_t px, py;
   tile_pixel(a.width, px, py);
   const bool active = px < a.width && py < a.height;
@@ -402,7 +410,7 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
       R t;
       uint32_t best;
       if constexpr (LINEAR)
-        traverse_linear(sc, ray, R(0.001), rng, t, best, cnt);
+        traverse_linear(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
       else
         traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
       RT_STAMP(3);
@@ -414,13 +422,19 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
       } else {
         cnt.template inc<ST_CLOSEST>();
         HitRec<R> h;
-        make_hit_record(sc, best, ray, t, false, h);
+        Material<R> mat;
+        if constexpr (LINEAR) {
+          lin_hit_record(sc, s_lin + best * LIN_DWORDS, ray, t, h, mat);
+        } else {
+          make_hit_record(sc, best, ray, t, false, h);
+          mat = sc.materials[h.material];
+        }
         RT_STAMP(4);
 #ifdef RT_ABL_NOSHADE
         L = L + thr * h.normal;
         cont = false;
 #else
-        cont = shade(sc, h, ray, thr, L, rng, cnt);
+        cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
 #endif
       }
       RT_STAMP(5);

@@ -67,10 +67,20 @@ template <typename R> struct alignas(4 * sizeof(R)) Op {
   R d[4];  // offset xyz | quaternion wxyz | neg_inv_density
 };
 constexpr uint32_t MATF_NEEDS_UV = 1u;  // some texture below this material reads hit.uv (Image / UV)
+constexpr uint32_t MATF_SOLID = 2u;     // the texture is Texture::Solid: its colour is copied into `color`
 template <typename R> struct Material {
   uint32_t tag, texture, flags, pad;
   R p[4];
+  R color[3], pad2;
 };
+
+// Leaf-list records (f32, small scenes): one fixed 48-dword record per leaf, copied into LDS at
+// kernel start so the traversal loop, the hit record and solid-colour shading read no global
+// memory and follow no dependent pointer chain.
+constexpr uint32_t LIN_DWORDS = 48, LIN_MAX_LEAVES = 16, LDS_MAX_LIGHTS = 8;
+constexpr uint32_t LIN_FLAGS = 0, LIN_REF = 1, LIN_NID = 2, LIN_OBJECT = 3, LIN_M = 4, LIN_B = 13, LIN_PRIM = 16,
+                   LIN_MAT = 24;  // Material<float> image: 12 dwords
+constexpr uint32_t LINF_XF = 1u, LINF_CUBE = 2u, LINF_MEDIUM = 4u;
 template <typename R> struct Texture {
   uint32_t tag, odd, even, width, height, pad;
   uint64_t texel_offset;
@@ -97,8 +107,8 @@ template <typename R> struct SceneView {
   const Texture<R>* textures;
   const uint8_t* texels;
   const Light<R>* lights;
-  const uint32_t* linear;  // leaf refs in BVH left-first DFS order (small scenes only)
-  uint32_t n_linear;       // 0 = scene too large for the leaf-list path
+  const uint32_t* linear_rec;  // n_linear leaf records (LIN_DWORDS each) in BVH left-first DFS order
+  uint32_t n_linear;           // 0 = scene not eligible for the leaf-list path
   uint32_t root;
   uint32_t lights_kind, n_lights;
   R background[3];

@@ -165,6 +165,12 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
     mats[i].texture = d.mat_texture[i];
     mats[i].pad = 0;
     mats[i].flags = (d.mat_texture[i] < d.n_textures && tex_uv[d.mat_texture[i]]) ? MATF_NEEDS_UV : 0u;
+    mats[i].pad2 = R(0);
+    for (int k = 0; k < 3; ++k) mats[i].color[k] = R(0);
+    if (d.mat_texture[i] < d.n_textures && d.tex_tag[d.mat_texture[i]] == RT_TEX_SOLID) {
+      mats[i].flags |= MATF_SOLID;
+      for (int k = 0; k < 3; ++k) mats[i].color[k] = conv<R>(d.tex_color[3 * (size_t)d.mat_texture[i] + k]);
+    }
     for (int k = 0; k < 4; ++k) mats[i].p[k] = conv<R>(d.mat_params[4 * (size_t)i + k]);
   }
   std::vector<Texture<R>> texs(d.n_textures);
@@ -256,9 +262,50 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
   UP(texs, textures)
   UP(texels, texels)
   UP(lights, lights)
-  UP(linear, linear)
+  // leaf-list records (see device/scene_view.hpp LIN_*): f32 only
+  std::vector<uint32_t> linear_rec;
+  if constexpr (sizeof(R) == 4) {
+    linear_rec.assign(linear.size() * LIN_DWORDS, 0u);
+    auto put = [&](size_t k, uint32_t off, float v) { std::memcpy(&linear_rec[k * LIN_DWORDS + off], &v, 4); };
+    for (size_t k = 0; k < linear.size(); ++k) {
+      uint32_t ref = linear[k], body = ref, flags = 0, material = 0, object = 0;
+      float nid = 0.0f;
+      if (RT_REF_KIND(ref) == RT_LEAF_COMPLEX) {
+        const uint32_t ci = RT_REF_INDEX(ref);
+        const Complex& cx = complexes[ci];
+        body = cx.body;
+        object = cx.object;
+        if (cx.n_rotate + cx.n_translate) flags |= LINF_XF | (cx.n_rotate << 16) | (cx.n_translate << 24);
+        for (int c = 0; c < 9; ++c) put(k, LIN_M + c, (float)xfs[ci].m_full[c]);
+        for (int c = 0; c < 3; ++c) put(k, LIN_B + c, (float)xfs[ci].b_full[c]);
+        if (cx.medium_pos != REF_NONE) {
+          flags |= LINF_MEDIUM;
+          nid = (float)xfs[ci].neg_inv_density;
+          material = cx.material;
+        }
+      }
+      const uint32_t bi = RT_REF_INDEX(body);
+      if (RT_REF_KIND(body) == RT_LEAF_CUBE) {
+        flags |= LINF_CUBE;
+        for (int c = 0; c < 6; ++c) put(k, LIN_PRIM + c, (float)d.cube[6 * (size_t)bi + c]);
+        if (!(flags & LINF_MEDIUM)) material = d.cube_material[bi];
+        if (RT_REF_KIND(ref) != RT_LEAF_COMPLEX) object = d.cube_object[bi];
+      } else {
+        for (int c = 0; c < 4; ++c) put(k, LIN_PRIM + c, (float)d.sphere[4 * (size_t)bi + c]);
+        if (!(flags & LINF_MEDIUM)) material = d.sphere_material[bi];
+        if (RT_REF_KIND(ref) != RT_LEAF_COMPLEX) object = d.sphere_object[bi];
+      }
+      linear_rec[k * LIN_DWORDS + LIN_FLAGS] = flags;
+      linear_rec[k * LIN_DWORDS + LIN_REF] = ref;
+      put(k, LIN_NID, nid);
+      linear_rec[k * LIN_DWORDS + LIN_OBJECT] = object;
+      static_assert(sizeof(Material<float>) == 12 * 4, "LIN_MAT image is 12 dwords");
+      if constexpr (sizeof(R) == 4) std::memcpy(&linear_rec[k * LIN_DWORDS + LIN_MAT], &mats[material], sizeof(Material<float>));
+    }
+  }
+  UP(linear_rec, linear_rec)
 #undef UP
-  s.view.n_linear = (uint32_t)linear.size();
+  s.view.n_linear = sizeof(R) == 4 ? (uint32_t)linear.size() : 0u;
   s.view.root = d.root;
   s.view.lights_kind = d.lights_kind;
   s.view.n_lights = d.n_lights;
@@ -323,6 +370,7 @@ bool leaf_world_bounds(const rt_scene_desc& d, const std::vector<Complex>& compl
   };
   if (RT_REF_KIND(ref) != RT_LEAF_COMPLEX) return prim_box(ref, lo, hi);
   const Complex& cx = complexes[RT_REF_INDEX(ref)];
+  if (cx.medium_pos != REF_NONE && cx.medium_pos != 0) return false;  // leaf-list records keep media outermost
   double plo[3], phi[3];
   if (!prim_box(cx.body, plo, phi)) return false;
   for (int c = 0; c < 3; ++c) {
@@ -353,7 +401,6 @@ bool leaf_world_bounds(const rt_scene_desc& d, const std::vector<Complex>& compl
 }
 
 constexpr uint32_t MAX_STACK_DEPTH = 64;
-constexpr uint32_t MAX_LINEAR_LEAVES = 16;  // scenes up to this many leaves take the leaf-list path (f32)
 constexpr uint32_t TARGET_WAVES = 256u * 16u;  // enough waves to fill 256 CUs at 4 waves/SIMD
 
 }  // namespace
@@ -524,7 +571,7 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
         continue;
       }
       linear.push_back(cur.ref);
-      if (linear.size() > MAX_LINEAR_LEAVES) ok = false;
+      if (linear.size() > LIN_MAX_LEAVES) ok = false;
       double lo[3], hi[3];
       if (ok && !leaf_world_bounds(*d, complexes, cur.ref, lo, hi)) ok = false;
       for (size_t a = 0; ok && a < path.size(); ++a) {
