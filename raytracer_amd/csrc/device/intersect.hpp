@@ -37,30 +37,27 @@ template <typename R> struct RayT {
 
 // ---- aabb.rs:17-34, with inv_d hoisted out of the per-node loop (the reference multiplies
 // by inv_d = 1/d, so hoisting is bit-identical) -------------------------------------------
+// The reference leaves the loop at the first axis whose interval is empty; the interval only
+// shrinks from axis to axis (max / min are monotone and ignore NaN), so "some axis failed" is
+// exactly "the final t_max <= t_min": all three axes are evaluated without branches and tested
+// once.  Same booleans, same t_min out.
 template <typename R>
 RT_DEV bool slab_hit(const R* lo, const R* hi, Vec3<R> o, Vec3<R> inv_d, R& t_min, R& t_max) {
-  {
-    R t0 = (lo[0] - o.x) * inv_d.x, t1 = (hi[0] - o.x) * inv_d.x;
-    if (inv_d.x < R(0)) { R s = t0; t0 = t1; t1 = s; }
-    t_min = rmax(t0, t_min);
-    t_max = rmin(t1, t_max);
-    if (t_max <= t_min) return false;
-  }
-  {
-    R t0 = (lo[1] - o.y) * inv_d.y, t1 = (hi[1] - o.y) * inv_d.y;
-    if (inv_d.y < R(0)) { R s = t0; t0 = t1; t1 = s; }
-    t_min = rmax(t0, t_min);
-    t_max = rmin(t1, t_max);
-    if (t_max <= t_min) return false;
-  }
-  {
-    R t0 = (lo[2] - o.z) * inv_d.z, t1 = (hi[2] - o.z) * inv_d.z;
-    if (inv_d.z < R(0)) { R s = t0; t0 = t1; t1 = s; }
-    t_min = rmax(t0, t_min);
-    t_max = rmin(t1, t_max);
-    if (t_max <= t_min) return false;
-  }
-  return true;
+  const R lx = lo[0], ly = lo[1], lz = lo[2], hx = hi[0], hy = hi[1], hz = hi[2];
+  R t0 = (lx - o.x) * inv_d.x, t1 = (hx - o.x) * inv_d.x;
+  R lo_t = rmax(inv_d.x < R(0) ? t1 : t0, t_min);
+  R hi_t = rmin(inv_d.x < R(0) ? t0 : t1, t_max);
+  t0 = (ly - o.y) * inv_d.y;
+  t1 = (hy - o.y) * inv_d.y;
+  lo_t = rmax(inv_d.y < R(0) ? t1 : t0, lo_t);
+  hi_t = rmin(inv_d.y < R(0) ? t0 : t1, hi_t);
+  t0 = (lz - o.z) * inv_d.z;
+  t1 = (hz - o.z) * inv_d.z;
+  lo_t = rmax(inv_d.z < R(0) ? t1 : t0, lo_t);
+  hi_t = rmin(inv_d.z < R(0) ? t0 : t1, hi_t);
+  t_min = lo_t;
+  t_max = hi_t;
+  return !(hi_t <= lo_t);
 }
 
 // ---- hittable.rs:257-276 (Sphere) -------------------------------------------------------
@@ -95,7 +92,7 @@ RT_DEV bool sphere_t<float>(Vec3<float> o, Vec3<float> d, float a, Vec3<float> c
   const double a64 = dx * dx + dy * dy + dz * dz;
   const double disc = half_b * half_b - a64 * cc;
   if (disc < 0.0) return false;
-  const double sqrtd = (double)sqrtf((float)disc);
+  const double sqrtd = (double)rroot((float)disc);
   const float inv_a = rrcp(a);
   float root = (float)(-half_b - sqrtd) * inv_a;
   if (root < t_min || root > t_max) {
@@ -293,7 +290,9 @@ RT_DEV bool lin_prim_t(const float* rec, uint32_t flags, Vec3<float> o, Vec3<flo
   return h;
 }
 
-template <bool STATS>
+// MEDIA = false compiles the loop without the constant-medium arm, so the RNG state is not
+// loop-carried (no per-iteration register copies) in scenes that have no medium.
+template <bool STATS, bool MEDIA>
 RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, const RayT<float>& r, float t_min, Rng& rng,
                             float& closest, uint32_t& best_k, Cnt<STATS>& cnt) {
   closest = Consts<float>::inf;
@@ -317,7 +316,7 @@ RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, const RayT<floa
     }
     float t;
     bool h;
-    if (!(flags & LINF_MEDIUM)) {
+    if (!MEDIA || !(flags & LINF_MEDIUM)) {
       h = lin_prim_t(rec, flags, o, d, inv_d, a, t_min, closest, t, cnt);
     } else {  // hittable.rs:319-349
       cnt.template inc<ST_MEDIUM>();

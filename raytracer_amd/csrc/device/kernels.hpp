@@ -409,9 +409,12 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
       RT_STAMP(2);
       R t;
       uint32_t best;
-      if constexpr (LINEAR)
-        traverse_linear(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
-      else
+      if constexpr (LINEAR) {
+        if (sc.linear_has_media)  // wave-uniform
+          traverse_linear<STATS, true>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+        else
+          traverse_linear<STATS, false>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+      } else
         traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
       RT_STAMP(3);
       bool cont;

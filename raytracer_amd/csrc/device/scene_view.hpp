@@ -109,6 +109,7 @@ template <typename R> struct SceneView {
   const Light<R>* lights;
   const uint32_t* linear_rec;  // n_linear leaf records (LIN_DWORDS each) in BVH left-first DFS order
   uint32_t n_linear;           // 0 = scene not eligible for the leaf-list path
+  uint32_t linear_has_media;   // some leaf record carries LINF_MEDIUM
   uint32_t root;
   uint32_t lights_kind, n_lights;
   R background[3];

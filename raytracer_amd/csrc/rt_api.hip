@@ -306,6 +306,9 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
   UP(linear_rec, linear_rec)
 #undef UP
   s.view.n_linear = sizeof(R) == 4 ? (uint32_t)linear.size() : 0u;
+  s.view.linear_has_media = 0;
+  for (size_t k = 0; k < linear_rec.size() / LIN_DWORDS; ++k)
+    if (linear_rec[k * LIN_DWORDS + LIN_FLAGS] & LINF_MEDIUM) s.view.linear_has_media = 1;
   s.view.root = d.root;
   s.view.lights_kind = d.lights_kind;
   s.view.n_lights = d.n_lights;
