@@ -109,6 +109,7 @@ struct Hittable {
   enum Kind { Cube, Sphere, MovingSphere, ConstantMedium, Translate, Rotate, List, Bvh, Empty };
   Kind kind = Empty;
   uint32_t object_id = NO_OBJECT;
+  uint32_t owner_id = NO_OBJECT;  // world-level object this node belongs to (keys the medium draw)
 
   V3 p0, p1;                         // Cube
   V3 center;                         // Sphere
@@ -132,6 +133,7 @@ struct Hittable {
     Hittable h;
     h.kind = kind;
     h.object_id = object_id;
+    h.owner_id = owner_id;
     h.p0 = p0;
     h.p1 = p1;
     h.center = center;
@@ -209,6 +211,14 @@ struct Hittable {
     h.kind = List;
     h.list = std::move(v);
     return h;
+  }
+
+  void set_owner(uint32_t id) {
+    owner_id = id;
+    if (child) child->set_owner(id);
+    for (auto& e : list) e.set_owner(id);
+    if (left) left->set_owner(id);
+    if (right) right->set_owner(id);
   }
 
   // hittable.rs:66-72
@@ -423,7 +433,7 @@ struct Hittable {
         hit1.t = std::fmax(hit1.t, 0.0);
         double ray_length = length(r.direction);
         double distance_inside_boundary = (hit2.t - hit1.t) * ray_length;
-        double hit_distance = neg_inv_density * std::log(rng.next_f64());
+        double hit_distance = neg_inv_density * std::log(rng.keyed_f64(owner_id));
         if (hit_distance > distance_inside_boundary) return false;
         double t = hit1.t + hit_distance / ray_length;
         V3 p = r.at(t);

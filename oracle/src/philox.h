@@ -71,6 +71,14 @@ struct Rng {
     ++draws;
     return r;
   }
+  // A draw that belongs to one constant medium of the current slot: word 0 of block
+  // 0x80000000 | object id.  Keyed, not sequential, so it does not depend on the order in which a
+  // traversal reaches the media (stands in for rand::random() at hittable.rs:342).
+  double keyed_f64(uint32_t object_id) {
+    Philox4 r = philox4x32_10(a, b, c, 0x80000000u | object_id, k0, k1);
+    ++draws;
+    return (double)r.v[0] * (1.0 / 4294967296.0);
+  }
   // uniform [0,1): one 32-bit word, exact in f64 (stands in for rand's gen::<f64>()).
   double next_f64() { return (double)next_u32() * (1.0 / 4294967296.0); }
   // uniform [lo,hi) (stands in for gen_range(lo..hi) on f64).

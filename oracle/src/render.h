@@ -40,7 +40,10 @@ inline Scene build_scene(const SceneSpec& spec, double aspect_ratio, uint64_t bv
   if (rotate_bbox_override == 0) sc.rotate_bbox = RotateBBox::Reference;
   if (rotate_bbox_override == 1) sc.rotate_bbox = RotateBBox::Correct;
   sc.n_objects = (uint32_t)def.world.size();
-  for (uint32_t i = 0; i < def.world.size(); ++i) def.world[i].object_id = i;
+  for (uint32_t i = 0; i < def.world.size(); ++i) {
+    def.world[i].object_id = i;
+    def.world[i].set_owner(i);
+  }
 
   // main.rs:125
   BuildCtx ctx;

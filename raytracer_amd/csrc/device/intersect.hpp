@@ -217,7 +217,7 @@ RT_DEV bool complex_t(const SceneView<R>& sc, uint32_t idx, const RayT<R>& r, R 
   t1 = rmax(t1, R(0));
   R ray_length = length(dm);
   R distance_inside_boundary = (t2 - t1) * ray_length;
-  R hit_distance = neg_inv_density * rlog(rng.next<R>());
+  R hit_distance = neg_inv_density * rlog(rng.template keyed<R>(cx.object));
   if (hit_distance > distance_inside_boundary) return false;
   t_out = t1 + rdiv(hit_distance, ray_length);
   return true;
@@ -261,6 +261,93 @@ RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng
     if (sp == 0) break;
     --sp;
     cur = stack[sp * stride];
+  }
+}
+
+// ORDERED walk (f32 production path for scenes too large for the leaf list).
+//
+// The reference always descends left first, so on a large scene it wades through hundreds of
+// nodes behind the nearest hit.  The result it computes is nevertheless order-independent: every
+// leaf yields a candidate t that does not depend on the t_max it is given (sphere: nearest root
+// >= t_min; cube: entry t; medium: boundary entry + a draw KEYED by the object), the winner is the
+// smallest candidate, and among equal candidates the leaf reached first by the left-first DFS,
+// i.e. the one with the smallest DFS rank.  So: visit the nearer child first, cull popped entries
+// whose box entry is beyond the current closest, keep the bounds inclusive (next float above
+// `closest`) and break exact ties by the stored DFS rank — same winner as hittable.rs:400-412,
+// a fraction of the node visits.
+RT_DEV uint32_t leaf_rank(const SceneView<float>& sc, uint32_t ref) {
+  const uint32_t k = ref_kind(ref), i = ref_index(ref);
+  if (k == LEAF_SPHERE) return sc.sphere_attr[i].rank;
+  if (k == LEAF_MSPHERE) return sc.msphere_attr[i].rank;
+  if (k == LEAF_CUBE) return sc.cube_attr[i].rank;
+  return sc.complexes[i].rank;
+}
+RT_DEV float next_up(float x) {  // smallest float above a positive finite x; +inf stays +inf
+  return x < Consts<float>::inf ? __uint_as_float(__float_as_uint(x) + 1u) : x;
+}
+
+template <bool STATS>
+RT_DEV void traverse_ordered(const SceneView<float>& sc, const RayT<float>& r, float t_min, Rng& rng,
+                             uint32_t* stack, uint32_t stride, uint32_t depth, float& closest, uint32_t& best,
+                             Cnt<STATS>& cnt) {
+  closest = Consts<float>::inf;
+  best = REF_NONE;
+  uint32_t cur = sc.root;
+  if (cur == REF_NONE) return;
+  float* stack_t = reinterpret_cast<float*>(stack + depth * stride);  // entry distances, same shape
+  const Vec3<float> inv_d = inverse3(r.d);
+  const float a = sqrlen(r.d);
+  uint32_t sp = 0;
+  for (;;) {
+    const float t_incl = next_up(closest);
+    if (!(cur & REF_LEAF)) {
+      cnt.template inc<ST_NODES>(2);
+      const Node2 n = sc.nodes2[cur];
+      float l0 = t_min, l1 = t_incl, r0 = t_min, r1 = t_incl;
+      bool hl = slab_hit(n.lbox, n.lbox + 3, r.o, inv_d, l0, l1);
+      bool hr = slab_hit(n.rbox, n.rbox + 3, r.o, inv_d, r0, r1);
+      if (n.flags & 1u) {
+        if (!hl) l0 = t_min;
+        hl = true;
+      }
+      if (n.flags & 2u) {
+        if (!hr) r0 = t_min;
+        hr = true;
+      }
+      if (hl && hr) {
+        const bool left_first = l0 <= r0;
+        stack[sp * stride] = left_first ? n.right : n.left;
+        stack_t[sp * stride] = left_first ? r0 : l0;
+        ++sp;
+        cur = left_first ? n.left : n.right;
+        continue;
+      }
+      if (hl || hr) {
+        cur = hl ? n.left : n.right;
+        continue;
+      }
+    } else {
+      float t;
+      bool h;
+      if (ref_kind(cur) == LEAF_COMPLEX)
+        h = complex_t(sc, ref_index(cur), r, t_min, t_incl, rng, t, cnt);
+      else
+        h = prim_t(sc, cur, r, inv_d, a, t_min, t_incl, t, cnt);
+      if (h) {
+        bool take = t < closest;
+        if (t == closest && best != REF_NONE) take = leaf_rank(sc, cur) < leaf_rank(sc, best);
+        if (take) {
+          closest = t;
+          best = cur;
+        }
+      }
+    }
+    for (;;) {
+      if (sp == 0) return;
+      --sp;
+      cur = stack[sp * stride];
+      if (!(stack_t[sp * stride] > closest)) break;
+    }
   }
 }
 
@@ -331,7 +418,7 @@ RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, const RayT<floa
           if (t1 < t2) {
             t1 = rmax(t1, 0.0f);
             const float ray_length = length(r.d);  // rigid maps keep |d|
-            const float hit_distance = rec[LIN_NID] * rlog(rng.next<float>());
+            const float hit_distance = rec[LIN_NID] * rlog(rng.keyed<float>(__float_as_uint(rec[LIN_OBJECT])));
             if (!(hit_distance > (t2 - t1) * ray_length)) {
               t = t1 + rdiv(hit_distance, ray_length);
               h = true;

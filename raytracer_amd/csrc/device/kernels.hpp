@@ -333,12 +333,17 @@ struct RenderArgs {
   uint32_t max_depth;
   uint32_t accumulate;  // add to accum instead of overwriting it (ignored when splits > 1: always atomic add)
   uint32_t splits;      // gridDim.y: each block row renders a slice of the launch's samples
+  uint32_t stack_depth; // LDS traversal-stack entries per lane
   uint64_t seed;
 };
 
-template <typename R, bool STATS, bool EARLY_EXIT, bool LINEAR>
+// TRAV: 0 = the reference's left-first BVH walk, 1 = leaf list (small scenes), 2 = ordered BVH walk
+constexpr int TRAV_REFERENCE = 0, TRAV_LINEAR = 1, TRAV_ORDERED = 2;
+
+template <typename R, bool STATS, bool EARLY_EXIT, int TRAV>
 __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
                                                        R* __restrict__ accum, DeviceStats* stats) {
+  constexpr bool LINEAR = TRAV == TRAV_LINEAR;
   extern __shared__ uint32_t lds_stack[];
   uint32_t* stack = lds_stack + threadIdx.x;
   // small read-mostly tables staged in LDS once per workgroup: the lights, and (leaf-list path)
@@ -414,8 +419,11 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
           traverse_linear<STATS, true>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
         else
           traverse_linear<STATS, false>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
-      } else
+      } else if constexpr (TRAV == TRAV_ORDERED) {
+        traverse_ordered(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, a.stack_depth, t, best, cnt);
+      } else {
         traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+      }
       RT_STAMP(3);
       bool cont;
       if (best == REF_NONE) {  // main.rs:104

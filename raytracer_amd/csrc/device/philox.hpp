@@ -83,6 +83,11 @@ struct Rng {
     --have;
     return r;
   }
+  // The draw of one constant medium in the current slot: word 0 of block 0x80000000 | object id.
+  // Keyed instead of sequential, so any traversal order gives every medium the same draw.
+  template <typename R> RT_DEV R keyed(uint32_t object_id) const {
+    return u01<R>(philox4x32_10(pixel, sample, slot, 0x80000000u | object_id, k0, k1).x);
+  }
   template <typename R> RT_DEV R next() { return u01<R>(next_u32()); }
   template <typename R> RT_DEV R range(R lo, R hi) { return lo + (hi - lo) * next<R>(); }
   RT_DEV uint32_t below(uint32_t n) { return __umulhi(next_u32(), n); }

@@ -49,10 +49,21 @@ template <typename R> struct alignas(4 * sizeof(R)) Cube {  // hittable.rs:42-47
 };
 struct Attr {  // cold per-primitive attributes
   uint32_t material, object;
+  uint32_t rank;  // position of this leaf in the reference's left-first DFS order (tie-break)
+  uint32_t pad;
+};
+// Node of the ORDERED walk (f32): the boxes of BOTH children next to their references, so one
+// 64-byte fetch decides which child is nearer.  flags bit 0 / 1: the left / right child is a leaf
+// whose box is only an ordering hint, not a proven bound (never cull by it).
+struct alignas(64) Node2 {
+  float lbox[6];
+  float rbox[6];
+  uint32_t left, right, flags, pad;
 };
 struct Complex {
   uint32_t body, op_first, op_count, medium_pos;  // medium_pos = index of the MEDIUM op in the chain, or REF_NONE
   uint32_t material, object, n_rotate, n_translate;
+  uint32_t rank, pad[3];
 };
 // The wrapper chain of a complex object composed on the host (in f64) into rigid maps
 // local = M * world + b.  `full` takes a world ray into the primitive's frame, `outer` into the
@@ -93,6 +104,7 @@ template <typename R> struct Light {
 
 template <typename R> struct SceneView {
   const Node<R>* nodes;
+  const Node2* nodes2;  // ordered walk (f32 side only)
   const Real4<R>* spheres;
   const MSphere<R>* mspheres;
   const Cube<R>* cubes;

@@ -23,23 +23,34 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   a.seed = seed;
   dim3 grid(shape.tiles, shape.splits, 1), block(BLOCK, 1, 1);
   size_t lds = (size_t)shape.stack_depth * BLOCK * sizeof(uint32_t);
+  a.stack_depth = shape.stack_depth;
 #if RT_HAS_LINEAR
-  if (shape.linear) {
+  if (shape.trav == TRAV_LINEAR) {
     if (stats)
-      hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, true>), grid, block, 0, st, sc, cam, a, accum,
-                         dstats);
+      hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_LINEAR>), grid, block, 0, st, sc, cam, a,
+                         accum, dstats);
     else
-      hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, true>), grid, block, 0, st, sc, cam, a, accum,
-                         dstats);
+      hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_LINEAR>), grid, block, 0, st, sc, cam, a,
+                         accum, dstats);
+    return hipGetLastError();
+  }
+  if (shape.trav == TRAV_ORDERED) {
+    const size_t lds2 = 2 * lds;  // refs + entry distances
+    if (stats)
+      hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_ORDERED>), grid, block, lds2, st, sc, cam,
+                         a, accum, dstats);
+    else
+      hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_ORDERED>), grid, block, lds2, st, sc, cam,
+                         a, accum, dstats);
     return hipGetLastError();
   }
 #endif
   if (stats)
-    hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, false>), grid, block, lds, st, sc, cam, a, accum,
-                       dstats);
+    hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
+                       accum, dstats);
   else
-    hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, false>), grid, block, lds, st, sc, cam, a, accum,
-                       dstats);
+    hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
+                       accum, dstats);
   return hipGetLastError();
 }
 

@@ -93,6 +93,16 @@ struct DeviceBuffers {
   }
 };
 
+// What rt_scene_create learns from one left-first DFS of the tree.
+struct TreeFacts {
+  std::vector<uint32_t> rank_sphere, rank_msphere, rank_cube, rank_complex;  // DFS rank per leaf
+  std::vector<float> leaf_box;      // [n_leaves by rank][6], rounded outward (ordering / culling in the ordered walk)
+  std::vector<uint32_t> leaf_refs;  // by rank
+  bool conservative = true;         // every node box bounds the node boxes and leaves below it
+  double t_lo = -INFINITY, t_hi = INFINITY;  // ... for ray times in [t_lo, t_hi] (moving spheres)
+  bool linear_ok = true;            // additionally: few leaves, no moving sphere, media outermost
+};
+
 template <typename R> struct SceneSide {
   DeviceBuffers bufs;
   SceneView<R> view{};
@@ -100,7 +110,7 @@ template <typename R> struct SceneSide {
 
 template <typename R>
 hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& complexes, const std::vector<uint32_t>& linear,
-                      SceneSide<R>& s) {
+                      const TreeFacts& facts, SceneSide<R>& s) {
   std::vector<Node<R>> nodes(d.n_nodes);
   for (uint32_t i = 0; i < d.n_nodes; ++i) {
     std::memset(&nodes[i], 0, sizeof(Node<R>));
@@ -111,12 +121,40 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
     nodes[i].left = d.node_left[i];
     nodes[i].right = d.node_right[i];
   }
+  // ordered-walk nodes (f32): both children's boxes beside their references
+  std::vector<Node2> nodes2;
+  if constexpr (sizeof(R) == 4) {
+    if (facts.conservative) {
+      nodes2.resize(d.n_nodes);
+      auto child_box = [&](uint32_t ref, float* out) {
+        if (ref & RT_REF_LEAF) {
+          const uint32_t k = RT_REF_KIND(ref), i = RT_REF_INDEX(ref);
+          const uint32_t rank = k == RT_LEAF_SPHERE ? facts.rank_sphere[i] : k == RT_LEAF_MSPHERE ? facts.rank_msphere[i]
+                                : k == RT_LEAF_CUBE ? facts.rank_cube[i] : facts.rank_complex[i];
+          for (int c = 0; c < 6; ++c) out[c] = facts.leaf_box[6 * (size_t)rank + c];
+        } else {
+          for (int c = 0; c < 3; ++c) {
+            out[c] = conv_down(d.node_box[6 * (size_t)ref + c]);
+            out[3 + c] = conv_up(d.node_box[6 * (size_t)ref + 3 + c]);
+          }
+        }
+      };
+      for (uint32_t i = 0; i < d.n_nodes; ++i) {
+        std::memset(&nodes2[i], 0, sizeof(Node2));
+        child_box(d.node_left[i], nodes2[i].lbox);
+        child_box(d.node_right[i], nodes2[i].rbox);
+        nodes2[i].left = d.node_left[i];
+        nodes2[i].right = d.node_right[i];
+        nodes2[i].flags = 0;  // with verified-conservative boxes every leaf box may cull
+      }
+    }
+  }
   std::vector<Real4<R>> spheres(d.n_spheres);
   std::vector<Attr> sphere_attr(d.n_spheres);
   for (uint32_t i = 0; i < d.n_spheres; ++i) {
     const double* p = d.sphere + 4 * (size_t)i;
     spheres[i] = Real4<R>{conv<R>(p[0]), conv<R>(p[1]), conv<R>(p[2]), conv<R>(p[3])};
-    sphere_attr[i] = Attr{d.sphere_material[i], d.sphere_object[i]};
+    sphere_attr[i] = Attr{d.sphere_material[i], d.sphere_object[i], facts.rank_sphere[i], 0};
   }
   std::vector<MSphere<R>> mspheres(d.n_mspheres);
   std::vector<Attr> msphere_attr(d.n_mspheres);
@@ -132,7 +170,7 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
     m.t0 = conv<R>(p[7]);
     m.t1 = conv<R>(p[8]);
     mspheres[i] = m;
-    msphere_attr[i] = Attr{d.msphere_material[i], d.msphere_object[i]};
+    msphere_attr[i] = Attr{d.msphere_material[i], d.msphere_object[i], facts.rank_msphere[i], 0};
   }
   std::vector<Cube<R>> cubes(d.n_cubes);
   std::vector<Attr> cube_attr(d.n_cubes);
@@ -145,7 +183,7 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
       c.p1[k] = conv<R>(p[3 + k]);
     }
     cubes[i] = c;
-    cube_attr[i] = Attr{d.cube_material[i], d.cube_object[i]};
+    cube_attr[i] = Attr{d.cube_material[i], d.cube_object[i], facts.rank_cube[i], 0};
   }
   std::vector<uint32_t> op_tag(d.n_ops);
   std::vector<Op<R>> ops(d.n_ops);
@@ -248,6 +286,7 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
 #define UP(vec, field) \
   if ((e = s.bufs.upload(vec, &s.view.field)) != hipSuccess) return e;
   UP(nodes, nodes)
+  UP(nodes2, nodes2)
   UP(spheres, spheres)
   UP(mspheres, mspheres)
   UP(cubes, cubes)
@@ -347,10 +386,10 @@ bool is_valid_leaf(uint32_t ref, const rt_scene_desc& d) {
   return RT_REF_KIND(ref) == RT_LEAF_COMPLEX && RT_REF_INDEX(ref) < d.n_complex;
 }
 
-// Conservative world-space bounds of a leaf, or false when they cannot be established here
-// (a moving sphere's extent depends on the ray times the camera will emit).
+// Conservative world-space bounds of a leaf.  A moving sphere is bounded over its own
+// [time_start, time_end] only; *t_lo / *t_hi are narrowed to the ray times for which the bounds hold.
 bool leaf_world_bounds(const rt_scene_desc& d, const std::vector<Complex>& complexes, uint32_t ref, double lo[3],
-                       double hi[3]) {
+                       double hi[3], double* t_lo = nullptr, double* t_hi = nullptr) {
   auto prim_box = [&](uint32_t r, double plo[3], double phi[3]) -> bool {
     const uint32_t k = RT_REF_KIND(r), i = RT_REF_INDEX(r);
     if (k == RT_LEAF_SPHERE) {
@@ -369,11 +408,22 @@ bool leaf_world_bounds(const rt_scene_desc& d, const std::vector<Complex>& compl
       }
       return true;
     }
+    if (k == RT_LEAF_MSPHERE) {  // centre moves linearly between c0 (time_start) and c1 (time_end)
+      const double* m = d.msphere + 9 * (size_t)i;
+      const double r = std::fabs(m[6]);
+      if (!(m[7] < m[8])) return false;
+      for (int c = 0; c < 3; ++c) {
+        plo[c] = std::fmin(m[c], m[3 + c]) - r;
+        phi[c] = std::fmax(m[c], m[3 + c]) + r;
+      }
+      if (t_lo) *t_lo = std::fmax(*t_lo, m[7]);
+      if (t_hi) *t_hi = std::fmin(*t_hi, m[8]);
+      return true;
+    }
     return false;
   };
   if (RT_REF_KIND(ref) != RT_LEAF_COMPLEX) return prim_box(ref, lo, hi);
   const Complex& cx = complexes[RT_REF_INDEX(ref)];
-  if (cx.medium_pos != REF_NONE && cx.medium_pos != 0) return false;  // leaf-list records keep media outermost
   double plo[3], phi[3];
   if (!prim_box(cx.body, plo, phi)) return false;
   for (int c = 0; c < 3; ++c) {
@@ -411,6 +461,8 @@ constexpr uint32_t TARGET_WAVES = 256u * 16u;  // enough waves to fill 256 CUs a
 struct rt_scene {
   int device = 0;
   uint32_t stack_depth = 1;
+  bool boxes_conservative = false;               // leaf-list / ordered walks allowed ...
+  double safe_t_lo = 0, safe_t_hi = 0;           // ... for cameras whose shutter lies in this window
   SceneSide<float> f32;
   SceneSide<double> f64;
   DeviceStats* dstats = nullptr;
@@ -550,50 +602,86 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
   if (device < 0 || device >= ndev) return fail(RT_ERR_BAD_ARG, "rt_scene_create: device %d of %d", device, ndev);
   HIP_TRY(hipSetDevice(device));
 
-  // Leaves in left-first DFS order (the order the reference's recursion reaches them), for the
-  // leaf-list path.  That path is only equivalent to the BVH walk when every node box really
-  // bounds the leaves below it; the reference's Rotate::bounding_box does not (it can
-  // clip the object), and then pruning is part of the result.  So: verify containment, and fall
-  // back to the BVH walk for any scene where a box is not conservative (or cannot be checked).
-  std::vector<uint32_t> linear;
+  // One left-first DFS (the order the reference's recursion reaches the leaves): DFS rank of every
+  // leaf, its bounds, and whether every box in the tree really bounds what is below it.  The
+  // reference's Rotate::bounding_box does not always (it can clip the object), and then
+  // pruning by that box is part of the image: only the reference-order walk reproduces it, so the
+  // leaf-list and ordered walks are enabled only for trees whose boxes are verified conservative.
+  TreeFacts facts;
+  facts.rank_sphere.assign(d->n_spheres, RT_REF_NONE);
+  facts.rank_msphere.assign(d->n_mspheres, RT_REF_NONE);
+  facts.rank_cube.assign(d->n_cubes, RT_REF_NONE);
+  facts.rank_complex.assign(d->n_complex, RT_REF_NONE);
   if (d->root != RT_REF_NONE) {
     struct Todo {
-      uint32_t ref, depth;
+      uint32_t ref, parent;
     };
-    std::vector<Todo> todo{{d->root, 0}};
-    std::vector<uint32_t> path;  // node indices from the root to the current position
-    bool ok = true;
-    while (!todo.empty() && ok) {
+    std::vector<Todo> todo{{d->root, RT_REF_NONE}};
+    auto inside = [&](const double lo[3], const double hi[3], uint32_t parent) {
+      if (parent == RT_REF_NONE) return true;
+      const double* nb = d->node_box + 6 * (size_t)parent;
+      for (int k = 0; k < 3; ++k) {
+        const double tol = 1e-9 * (1.0 + std::fabs(lo[k]) + std::fabs(hi[k]));
+        if (!(nb[k] <= lo[k] + tol && hi[k] <= nb[3 + k] + tol)) return false;
+      }
+      return true;
+    };
+    while (!todo.empty()) {
       Todo cur = todo.back();
       todo.pop_back();
-      path.resize(cur.depth);
       if (!(cur.ref & RT_REF_LEAF)) {
-        path.push_back(cur.ref);
-        todo.push_back({d->node_right[cur.ref], cur.depth + 1});
-        todo.push_back({d->node_left[cur.ref], cur.depth + 1});
+        const double* nb = d->node_box + 6 * (size_t)cur.ref;
+        if (!inside(nb, nb + 3, cur.parent)) facts.conservative = false;
+        todo.push_back({d->node_right[cur.ref], cur.ref});
+        todo.push_back({d->node_left[cur.ref], cur.ref});
         continue;
       }
-      linear.push_back(cur.ref);
-      if (linear.size() > LIN_MAX_LEAVES) ok = false;
-      double lo[3], hi[3];
-      if (ok && !leaf_world_bounds(*d, complexes, cur.ref, lo, hi)) ok = false;
-      for (size_t a = 0; ok && a < path.size(); ++a) {
-        const double* nb = d->node_box + 6 * (size_t)path[a];
-        for (int k = 0; k < 3; ++k) {
-          const double tol = 1e-9 * (1.0 + std::fabs(lo[k]) + std::fabs(hi[k]));
-          if (!(nb[k] <= lo[k] + tol && hi[k] <= nb[3 + k] + tol)) ok = false;
-        }
+      const uint32_t rank = (uint32_t)facts.leaf_refs.size();
+      facts.leaf_refs.push_back(cur.ref);
+      const uint32_t k = RT_REF_KIND(cur.ref), i = RT_REF_INDEX(cur.ref);
+      std::vector<uint32_t>& ranks = k == RT_LEAF_SPHERE ? facts.rank_sphere
+                                     : k == RT_LEAF_MSPHERE ? facts.rank_msphere
+                                     : k == RT_LEAF_CUBE ? facts.rank_cube : facts.rank_complex;
+      if (ranks[i] != RT_REF_NONE)
+        return fail(RT_ERR_BAD_ARG, "rt_scene_create: a leaf is referenced by more than one node");
+      ranks[i] = rank;
+      double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+      if (!leaf_world_bounds(*d, complexes, cur.ref, lo, hi, &facts.t_lo, &facts.t_hi)) {
+        facts.conservative = false;
+      } else if (!inside(lo, hi, cur.parent)) {
+        facts.conservative = false;
+      }
+      // The f32 kernels map the ray into a wrapped object's frame with rounded maps: give such a
+      // leaf's culling box a margin well above that rounding (culling only, never a hit test).
+      for (int c = 0; c < 3; ++c) {
+        const double pad = k == RT_LEAF_COMPLEX ? 4e-6 * (std::fabs(lo[c]) + std::fabs(hi[c]) + 1.0) : 0.0;
+        lo[c] -= pad;
+        hi[c] += pad;
+      }
+      for (int c = 0; c < 3; ++c) facts.leaf_box.push_back(conv_down(lo[c]));
+      for (int c = 0; c < 3; ++c) facts.leaf_box.push_back(conv_up(hi[c]));
+      if (k == RT_LEAF_MSPHERE) facts.linear_ok = false;
+      if (k == RT_LEAF_COMPLEX) {
+        const Complex& cx = complexes[i];
+        if (RT_REF_KIND(cx.body) == RT_LEAF_MSPHERE) facts.linear_ok = false;
+        if (cx.medium_pos != REF_NONE && cx.medium_pos != 0) facts.linear_ok = false;  // records keep media outermost
       }
     }
-    if (!ok) linear.clear();
   }
+  if (!facts.conservative || facts.leaf_refs.size() > LIN_MAX_LEAVES) facts.linear_ok = false;
+  std::vector<uint32_t> linear;
+  if (facts.linear_ok) linear = facts.leaf_refs;
+  for (uint32_t i = 0; i < d->n_complex; ++i) complexes[i].rank = facts.rank_complex[i];
 
   rt_scene* s = new rt_scene;
   s->device = device;
   s->stack_depth = std::max(tree_height, 1u);
   hipError_t e;
-  if ((e = build_side<float>(*d, complexes, linear, s->f32)) != hipSuccess ||
-      (e = build_side<double>(*d, complexes, linear, s->f64)) != hipSuccess ||
+  s->boxes_conservative = facts.conservative;
+  s->safe_t_lo = facts.t_lo;
+  s->safe_t_hi = facts.t_hi;
+  if ((e = build_side<float>(*d, complexes, linear, facts, s->f32)) != hipSuccess ||
+      (e = build_side<double>(*d, complexes, linear, facts, s->f64)) != hipSuccess ||
       (e = hipMalloc((void**)&s->dstats, sizeof(DeviceStats))) != hipSuccess ||
       (e = hipEventCreate(&s->ev0)) != hipSuccess || (e = hipEventCreate(&s->ev1)) != hipSuccess) {
     delete s;
@@ -620,9 +708,12 @@ int check_camera(const rt_camera* cam) {
   return RT_OK;
 }
 
-LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_samples, bool allow_linear = false) {
+LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_samples, bool f32_fast = false,
+                       const rt_camera* cam = nullptr) {
   LaunchShape sh;
-  sh.linear = allow_linear && s->f32.view.n_linear > 0;
+  sh.trav = 0;  // the reference's left-first walk: always valid
+  if (f32_fast && s->boxes_conservative && cam && cam->time_open >= s->safe_t_lo && cam->time_close <= s->safe_t_hi)
+    sh.trav = s->f32.view.n_linear > 0 ? 1 : (s->f32.view.root != RT_REF_NONE && !(s->f32.view.root & RT_REF_LEAF) ? 2 : 0);
   uint32_t tx = (w + 15) / 16, ty = (h + 15) / 16;
   sh.tiles = tx * ty;
   sh.stack_depth = s->stack_depth;
@@ -703,7 +794,7 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
   if (p->spp == 0 && !accumulate) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
   while (done < p->spp) {
     uint32_t n = std::min(per_launch, p->spp - done);
-    LaunchShape sh = make_shape(s, p->width, p->height, n, sizeof(R) == 4 && !(p->flags & RT_FLAG_FORCE_BVH));
+    LaunchShape sh = make_shape(s, p->width, p->height, n, sizeof(R) == 4 && !(p->flags & RT_FLAG_FORCE_BVH), cam);
     int acc = (accumulate || !first) ? 1 : 0;
     if (sh.splits > 1 && !acc) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
     HIP_TRY(Side<R>::render(sv, cv, p->width, p->height, (uint32_t)(p->sample_offset + done), n, p->max_depth, p->seed,

@@ -140,3 +140,23 @@ def test_leaf_list_path_refused_when_boxes_clip(earthmap):
     hs, ds, os_, h, depth = _pair("simple_light", earthmap)
     a, sa = ds.render(W, h, 4, depth, seed=5, stats=True)
     assert sa["nodes_visited"] > 0
+
+
+@pytest.mark.parametrize("name", ["random_scene", "final_scene", "bvh_stress", "earth"])
+def test_ordered_walk_equals_reference_walk(name, earthmap):
+    """Scenes too large for the leaf list take the near-child-first walk in f32 (verified-conservative
+    boxes only); RT_FLAG_FORCE_BVH takes the reference's left-first walk (hittable.rs:400-412).  Both run
+    the same leaf tests in the same f32 kernels; the winner is the smallest t with ties to the smaller
+    DFS rank, and medium draws are keyed by object, so the images agree except where a cull decision
+    hangs on the last ulp.  The ordered walk must also visit fewer nodes."""
+    hs, ds, os_, h, depth = _pair(name, earthmap)
+    a, sa = ds.render(W, h, 16, depth, seed=5, stats=True)
+    b, sb = ds.render(W, h, 16, depth, seed=5, stats=True, force_bvh=True)
+    for k in ("rays", "closest_hits", "diffuse_vertices", "specular_vertices", "emitter_hits", "misses"):
+        assert abs(sa[k] - sb[k]) <= 0.002 * max(sa[k], 1) + 2, (k, sa[k], sb[k])
+    print(f"{name}: nodes/ray ordered {sa['nodes_visited'] / sa['rays']:.1f}, reference {sb['nodes_visited'] / sb['rays']:.1f}")
+    if name == "random_scene":  # dense enough for near-first culling to pay at this size
+        assert sa["nodes_visited"] < sb["nodes_visited"]
+    same = np.isclose(a, b, rtol=1e-4, atol=1e-5).all(axis=-1)
+    assert same.mean() >= 0.98, f"{name}: only {same.mean():.4f} of pixels agree"
+    assert abs(a.sum() / b.sum() - 1.0) <= 0.01
