@@ -221,6 +221,16 @@ int rt_render_f64(rt_scene* scene, const rt_camera* cam, const rt_params* params
 int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
                      float* accum_rgb_device, int accumulate, void* stream, rt_stats* stats);
 
+/* Replaces: the same closure (main.rs:154-167) with rayon's worker pool (main.rs:157) lifted from
+ * cores to the GPUs of one node, in ONE process: one host thread per entry of `devices` builds its
+ * own device copy of the scene and renders samples [g*spp/G, (g+1)*spp/G) of every pixel (the
+ * union of the Philox streams does not depend on G); the shards are summed on devices[0] over
+ * xGMI peer copies and written to the HOST buffer accum_rgb ([h][w][3] f32 SUM).  A device may be
+ * listed more than once.  per_dev: null or G entries (per-shard counters and kernel time).
+ * One process per GPU + RCCL all-reduce (raytracer_amd/distributed.py) is the other way to do it. */
+int rt_render_multi(int n_dev, const int* devices, const rt_scene_desc* desc, const rt_camera* cam,
+                    const rt_params* params, float* accum_rgb, rt_stats* per_dev);
+
 /* Replaces: `pixel_color /= spp; pixel_from_color(pixel_color)` (main.rs:167-168, 51-63):
  * gamma 2, clamp [0, 0.9999], ×256, truncate; NaN → 0 like Rust's saturating `as u8`.    */
 void rt_tonemap(const float* accum_rgb, uint64_t n_pixels, uint64_t spp, uint8_t* rgb8);

@@ -151,6 +151,7 @@ inline double render(const Scene& sc, const RenderParams& p, double* accum, Coun
   uint32_t nthreads = p.threads ? p.threads : 1;
   std::vector<Counters> per_thread(nthreads);
   auto worker = [&](uint32_t tid) {
+    Counters* const saved = tls_counters();  // the calling thread keeps its own sink afterwards
     tls_counters() = &per_thread[tid];
     for (;;) {
       uint32_t y = next_row.fetch_add(1);
@@ -177,6 +178,7 @@ inline double render(const Scene& sc, const RenderParams& p, double* accum, Coun
         accum[3 * (size_t)pixel + 2] = pixel_color.z;
       }
     }
+    tls_counters() = saved;
   };
   std::vector<std::thread> pool;
   for (uint32_t t = 1; t < nthreads; ++t) pool.emplace_back(worker, t);

@@ -4,6 +4,6 @@ kernels behind a C ABI (include/rt.h), with a C++17 host layer (include/rt_host.
 Importing this package loads the in-tree native libraries and raises if they are missing:
 there is no CPU fallback."""
 from . import _ffi
-from .api import (SCENE_IDS, DeviceScene, HostScene, image_height, load_earthmap, render, tonemap)
+from .api import (SCENE_IDS, DeviceScene, HostScene, image_height, load_earthmap, render, render_multi, tonemap)
 
-__all__ = ["SCENE_IDS", "DeviceScene", "HostScene", "image_height", "load_earthmap", "render", "tonemap", "_ffi"]
+__all__ = ["SCENE_IDS", "DeviceScene", "HostScene", "image_height", "load_earthmap", "render", "render_multi", "tonemap", "_ffi"]

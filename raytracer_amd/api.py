@@ -164,6 +164,23 @@ class DeviceScene:
         return st.as_dict() if want_stats else None
 
 
+def render_multi(host_scene, devices, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0,
+                 stats=False, camera=None):
+    """rt_render_multi: one host thread per device, samples sharded, shards summed on devices[0].
+    Returns (accum SUM [h][w][3] float32, [per-device stats dict])."""
+    p = F.RtParams()
+    p.width, p.height, p.spp, p.max_depth = width, height, spp, max_depth
+    p.seed, p.sample_offset, p.spp_per_launch = seed, sample_offset, spp_per_launch
+    p.flags = F.RT_FLAG_STATS if stats else 0
+    devs = (C.c_int * len(devices))(*devices)
+    st = (F.RtStats * len(devices))()
+    accum = np.zeros((height, width, 3), dtype=np.float32)
+    cam = camera if camera is not None else host_scene.camera
+    F.check_hip(F.hip.rt_render_multi(len(devices), devs, C.byref(host_scene.desc), C.byref(cam), C.byref(p),
+                                      _ptr(accum), st))
+    return accum, [s.as_dict() for s in st]
+
+
 def tonemap(accum, spp):
     """main.rs:167-168 + 51-63: mean, gamma 2, clamp, quantise."""
     accum = np.ascontiguousarray(accum, dtype=np.float32)

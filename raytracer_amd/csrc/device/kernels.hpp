@@ -547,6 +547,13 @@ __global__ void tonemap_kernel(const float* __restrict__ accum, uint64_t n, floa
   }
 }
 
+// dst += src over n floats (n a multiple of 1 float; the accumulators of two devices' sample shards)
+__global__ void accum_add_kernel(float* __restrict__ dst, const float* __restrict__ src, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] += src[i];
+}
+
 #endif  // RT_DEFINE_COMMON
 
 template <typename R>

@@ -83,6 +83,13 @@ hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t
   hipLaunchKernelGGL(tonemap_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, accum, n, inv_spp, out);
   return hipGetLastError();
 }
+hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, hipStream_t st) {
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(accum_add_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, dst, src, n);
+  return hipGetLastError();
+}
 hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t* out, hipStream_t st) {
   hipLaunchKernelGGL(kat_philox_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, ctr, key, out);
   return hipGetLastError();

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt.h"
@@ -895,6 +896,77 @@ int rt_render_f64(rt_scene* s, const rt_camera* cam, const rt_params* p, double*
 int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* p, float* d_accum, int accumulate,
                      void* stream, rt_stats* stats) {
   return render_on_device<float>(s, cam, p, d_accum, accumulate, (hipStream_t)stream, stats);
+}
+
+// One host thread per device (rayon's "shared immutable scene, independent workers" model,
+// main.rs:157-169, lifted from cores to GPUs): device g renders samples [g*spp/G, (g+1)*spp/G) of
+// every pixel into its own HBM accumulator; the shards are then summed on devices[0].  Every peer
+// has its own xGMI link to devices[0], so the G-1 peer copies run in parallel, one per link; the
+// result is needed on ONE device (it goes to the host), so this is a reduce, not an all-reduce —
+// the process-per-GPU path (raytracer_amd/distributed.py) is the one that uses RCCL.
+int rt_render_multi(int n_dev, const int* devices, const rt_scene_desc* desc, const rt_camera* cam, const rt_params* p,
+                    float* accum, rt_stats* per_dev) {
+  if (n_dev < 1 || !devices || !desc || !p || !accum) return fail(RT_ERR_BAD_ARG, "rt_render_multi: bad argument");
+  if (int rc = check_camera(cam)) return rc;
+  if (n_dev > 64) return fail(RT_ERR_BAD_ARG, "rt_render_multi: at most 64 devices");
+  const size_t n_floats = (size_t)p->width * p->height * 3;
+  struct Shard {
+    rt_scene* scene = nullptr;
+    float* d_accum = nullptr;
+    int rc = RT_OK;
+    std::string err;
+  };
+  std::vector<Shard> shards((size_t)n_dev);
+  auto work = [&](int g) {
+    Shard& sh = shards[(size_t)g];
+    auto bail = [&](int rc) {
+      sh.rc = rc;
+      sh.err = g_err;
+    };
+    if (int rc = rt_scene_create(devices[g], desc, &sh.scene)) return bail(rc);
+    hipError_t e = hipMalloc((void**)&sh.d_accum, std::max<size_t>(n_floats * sizeof(float), 16));
+    if (e != hipSuccess) return bail(fail(RT_ERR_HIP, "rt_render_multi: hipMalloc: %s", hipGetErrorString(e)));
+    rt_params q = *p;  // samples [lo, hi) of every pixel: the union of the shards' Philox streams is
+    const uint64_t lo = (uint64_t)p->spp * (uint64_t)g / (uint64_t)n_dev;        // independent of n_dev
+    const uint64_t hi = (uint64_t)p->spp * (uint64_t)(g + 1) / (uint64_t)n_dev;
+    q.spp = (uint32_t)(hi - lo);
+    q.sample_offset = p->sample_offset + lo;
+    rt_stats local;
+    if (int rc = render_on_device<float>(sh.scene, cam, &q, sh.d_accum, 0, nullptr, per_dev ? &per_dev[g] : &local))
+      return bail(rc);
+  };
+  std::vector<std::thread> pool;
+  for (int g = 1; g < n_dev; ++g) pool.emplace_back(work, g);
+  work(0);
+  for (auto& t : pool) t.join();
+
+  int rc = RT_OK;
+  for (int g = 0; g < n_dev && rc == RT_OK; ++g)
+    if (shards[(size_t)g].rc != RT_OK) rc = fail(shards[(size_t)g].rc, "device %d: %s", devices[g], shards[(size_t)g].err.c_str());
+  // reduce onto devices[0]: peer copy into a staging buffer there, then dst += staging
+  float* staging = nullptr;
+  auto hip_ok = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_HIP, "rt_render_multi: %s: %s", what, hipGetErrorString(e));
+    return e == hipSuccess;
+  };
+  if (rc == RT_OK && hip_ok(hipSetDevice(devices[0]), "hipSetDevice")) {
+    if (n_dev > 1) hip_ok(hipMalloc((void**)&staging, std::max<size_t>(n_floats * sizeof(float), 16)), "hipMalloc");
+    for (int g = 1; g < n_dev && rc == RT_OK; ++g) {
+      if (!hip_ok(hipMemcpyPeer(staging, devices[0], shards[(size_t)g].d_accum, devices[g], n_floats * sizeof(float)),
+                  "hipMemcpyPeer"))
+        break;
+      hip_ok(launch_accum_add(shards[0].d_accum, staging, n_floats, nullptr), "accum_add");
+      hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
+    }
+    if (rc == RT_OK) hip_ok(hipMemcpy(accum, shards[0].d_accum, n_floats * sizeof(float), hipMemcpyDeviceToHost), "copy back");
+    if (staging) (void)hipFree(staging);
+  }
+  for (int g = 0; g < n_dev; ++g) {
+    Shard& sh = shards[(size_t)g];
+    if (sh.d_accum && hipSetDevice(devices[g]) == hipSuccess) (void)hipFree(sh.d_accum);
+    rt_scene_destroy(sh.scene);
+  }
+  return rc;
 }
 
 void rt_tonemap(const float* accum, uint64_t n_pixels, uint64_t spp, uint8_t* rgb8) {

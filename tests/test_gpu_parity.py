@@ -160,3 +160,20 @@ def test_ordered_walk_equals_reference_walk(name, earthmap):
     same = np.isclose(a, b, rtol=1e-4, atol=1e-5).all(axis=-1)
     assert same.mean() >= 0.98, f"{name}: only {same.mean():.4f} of pixels agree"
     assert abs(a.sum() / b.sum() - 1.0) <= 0.01
+
+
+def test_render_multi_equals_single_render(earthmap):
+    """rt_render_multi with the one GPU listed three times: three host threads, three scene copies,
+    three sample shards (sizes 10/11/11 of 32: uneven on purpose), summed on devices[0].  The union of
+    the shards' Philox streams is the single render's, so only the f32 summation order differs."""
+    import raytracer_amd as R
+    hs = R.HostScene(6, 1.0)
+    ds = R.DeviceScene(hs, 0)
+    one, s1 = ds.render(W, W, 32, 50, seed=9, sample_offset=3, stats=True)
+    multi, sm = R.render_multi(hs, [0, 0, 0], W, W, 32, 50, seed=9, sample_offset=3, stats=True)
+    assert sum(s["rays"] for s in sm) == s1["rays"]
+    np.testing.assert_allclose(multi, one, rtol=2e-5, atol=1e-5)
+    solo, _ = R.render_multi(hs, [0], W, W, 32, 50, seed=9, sample_offset=3)
+    np.testing.assert_allclose(solo, one, rtol=2e-5, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        R.render_multi(hs, [99], W, W, 4, 5)
