@@ -286,45 +286,48 @@ RT_DEV float next_up(float x) {  // smallest float above a positive finite x; +i
   return x < Consts<float>::inf ? __uint_as_float(__float_as_uint(x) + 1u) : x;
 }
 
-template <bool STATS>
-RT_DEV void traverse_ordered(const SceneView<float>& sc, const RayT<float>& r, float t_min, Rng& rng,
-                             uint32_t* stack, uint32_t stride, uint32_t depth, float& closest, uint32_t& best,
-                             Cnt<STATS>& cnt) {
-  closest = Consts<float>::inf;
-  best = REF_NONE;
-  uint32_t cur = sc.root;
-  if (cur == REF_NONE) return;
-  float* stack_t = reinterpret_cast<float*>(stack + depth * stride);  // entry distances, same shape
-  const Vec3<float> inv_d = inverse3(r.d);
-  const float a = sqrlen(r.d);
-  uint32_t sp = 0;
-  for (;;) {
+// The walk as a resumable state machine: the render kernel advances every lane of a wave one step at
+// a time and hands lanes whose walk has finished a new ray while the others keep walking (their
+// state stays in registers, their stack in LDS).
+struct OrderedWalk {
+  uint32_t cur, sp, best;
+  float closest;
+  Vec3<float> inv_d;
+  float a;
+
+  // returns false if there is nothing to walk (empty world)
+  RT_DEV bool start(const SceneView<float>& sc, const RayT<float>& r) {
+    closest = Consts<float>::inf;
+    best = REF_NONE;
+    cur = sc.root;
+    sp = 0;
+    inv_d = inverse3(r.d);
+    a = sqrlen(r.d);
+    return cur != REF_NONE;
+  }
+
+  // one node (both child boxes) or one leaf test, then the next entry; false when the walk is over
+  template <bool STATS>
+  RT_DEV bool step(const SceneView<float>& sc, const RayT<float>& r, float t_min, Rng& rng, uint32_t* stack,
+                   float* stack_t, uint32_t stride, Cnt<STATS>& cnt) {
     const float t_incl = next_up(closest);
     if (!(cur & REF_LEAF)) {
       cnt.template inc<ST_NODES>(2);
       const Node2 n = sc.nodes2[cur];
       float l0 = t_min, l1 = t_incl, r0 = t_min, r1 = t_incl;
-      bool hl = slab_hit(n.lbox, n.lbox + 3, r.o, inv_d, l0, l1);
-      bool hr = slab_hit(n.rbox, n.rbox + 3, r.o, inv_d, r0, r1);
-      if (n.flags & 1u) {
-        if (!hl) l0 = t_min;
-        hl = true;
-      }
-      if (n.flags & 2u) {
-        if (!hr) r0 = t_min;
-        hr = true;
-      }
+      const bool hl = slab_hit(n.lbox, n.lbox + 3, r.o, inv_d, l0, l1);
+      const bool hr = slab_hit(n.rbox, n.rbox + 3, r.o, inv_d, r0, r1);
       if (hl && hr) {
         const bool left_first = l0 <= r0;
         stack[sp * stride] = left_first ? n.right : n.left;
         stack_t[sp * stride] = left_first ? r0 : l0;
         ++sp;
         cur = left_first ? n.left : n.right;
-        continue;
+        return true;
       }
       if (hl || hr) {
         cur = hl ? n.left : n.right;
-        continue;
+        return true;
       }
     } else {
       float t;
@@ -343,13 +346,13 @@ RT_DEV void traverse_ordered(const SceneView<float>& sc, const RayT<float>& r, f
       }
     }
     for (;;) {
-      if (sp == 0) return;
+      if (sp == 0) return false;
       --sp;
       cur = stack[sp * stride];
-      if (!(stack_t[sp * stride] > closest)) break;
+      if (!(stack_t[sp * stride] > closest)) return true;
     }
   }
-}
+};
 
 // Small scenes (a handful of leaves): test every leaf in BVH left-first DFS order with the
 // same shrinking t_max and the same strict `<` — exactly the reference's List arm

@@ -338,6 +338,8 @@ struct RenderArgs {
 };
 
 // TRAV: 0 = the reference's left-first BVH walk, 1 = leaf list (small scenes), 2 = ordered BVH walk
+// run to completion per ray (kept as the A/B baseline of render_refill_kernel, which is what
+// LaunchShape::trav == 2 launches unless RT_ORDERED_NO_REFILL is set in the environment)
 constexpr int TRAV_REFERENCE = 0, TRAV_LINEAR = 1, TRAV_ORDERED = 2;
 
 template <typename R, bool STATS, bool EARLY_EXIT, int TRAV>
@@ -419,8 +421,14 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
           traverse_linear<STATS, true>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
         else
           traverse_linear<STATS, false>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
-      } else if constexpr (TRAV == TRAV_ORDERED) {
-        traverse_ordered(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, a.stack_depth, t, best, cnt);
+      } else if constexpr (TRAV == TRAV_ORDERED) {  // run-to-completion form of the ordered walk (A/B baseline)
+        OrderedWalk walk;
+        bool more = walk.start(sc, ray);
+        while (more)
+          more = walk.step(sc, ray, R(0.001), rng, stack, reinterpret_cast<float*>(stack + a.stack_depth * BLOCK),
+                           (uint32_t)BLOCK, cnt);
+        t = walk.closest;
+        best = walk.best;
       } else {
         traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
       }
@@ -466,6 +474,138 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
     if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)))
       for (int i = 0; i < 8; ++i) atomicAdd(&stats->stamp[i], stamp_acc[i]);
 #endif
+    R* out = accum + 3ull * pixel;
+    if (a.splits > 1) {
+      atomicAdd(out + 0, acc.x);
+      atomicAdd(out + 1, acc.y);
+      atomicAdd(out + 2, acc.z);
+    } else if (a.accumulate) {
+      out[0] += acc.x;
+      out[1] += acc.y;
+      out[2] += acc.z;
+    } else {
+      out[0] = acc.x;
+      out[1] = acc.y;
+      out[2] = acc.z;
+    }
+  }
+  flush_stats(cnt, stats);
+  uint32_t nf = wave_sum(nonfinite);
+  if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&stats->v[ST_NONFINITE], (unsigned long long)nf);
+}
+
+// Large scenes, f32: the ordered walk with in-wave ray refill.
+//
+// In a BVH-bound scene the number of walk steps per ray is heavy-tailed (1M spheres: mean ~170,
+// tail in the thousands), so a wave that walks "until its slowest lane is done" idles most lanes
+// most of the time (measured: 9 % VALU lane utilisation).  Here the walk is a per-lane state
+// machine (OrderedWalk): all lanes step together, and as soon as a quarter of the wave's unfinished
+// lanes have no ray left to walk, the wave leaves the step loop, shades exactly those lanes (hit
+// record, Material::scatter, next ray or next camera sample) and re-enters the loop with them
+// refilled — the lanes still walking keep their state in registers and their stack in LDS.  Same
+// paths, same draws as render_kernel: a lane's vertices are still processed in order.
+#ifndef RT_REFILL_SHIFT
+#define RT_REFILL_SHIFT 2  // refill when idle lanes >= unfinished lanes >> RT_REFILL_SHIFT
+#endif
+template <bool STATS>
+__global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_refill_kernel(SceneView<float> sc, CameraView<float> cam,
+                                                                                 RenderArgs a, float* __restrict__ accum,
+                                                                                 DeviceStats* stats) {
+  using R = float;
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  float* stack_t = reinterpret_cast<float*>(stack + a.stack_depth * BLOCK);
+  __shared__ Light<R> s_lights[LDS_MAX_LIGHTS];
+  {
+    const uint32_t n_l = sc.n_lights < LDS_MAX_LIGHTS ? sc.n_lights : LDS_MAX_LIGHTS;
+    constexpr uint32_t LW = sizeof(Light<R>) / 4;
+    for (uint32_t i = threadIdx.x; i < n_l * LW; i += BLOCK)
+      reinterpret_cast<uint32_t*>(s_lights)[i] = reinterpret_cast<const uint32_t*>(sc.lights)[i];
+    __syncthreads();
+  }
+  const Light<R>* lights = sc.n_lights <= LDS_MAX_LIGHTS ? s_lights : sc.lights;
+  uint32_t px, py;
+  tile_pixel(a.width, px, py);
+  const uint32_t pixel = py * a.width + px;
+
+  Cnt<STATS> cnt;
+  cnt.clear();
+  uint32_t nonfinite = 0;
+  Vec3<R> acc;
+  const Vec3<R> background(sc.background[0], sc.background[1], sc.background[2]);
+  uint32_t s = (uint32_t)(((uint64_t)a.n_samples * blockIdx.y) / a.splits);
+  const uint32_t s_end = (uint32_t)(((uint64_t)a.n_samples * (blockIdx.y + 1)) / a.splits);
+  bool done = !(px < a.width && py < a.height) || s == s_end || a.max_depth == 0;  // main.rs:73-75: depth 0 -> black
+  bool alive = false, walking = false;
+  RayT<R> ray;
+  Vec3<R> thr, L;
+  uint32_t depth_left = 0, slot = 0;
+  Rng rng;
+  rng.init(a.seed, pixel, 0);
+  OrderedWalk walk;
+  walk.cur = REF_NONE;
+  walk.sp = 0;
+  walk.best = REF_NONE;
+  walk.closest = 0.0f;
+  walk.a = 0.0f;
+
+  for (;;) {
+    // (1) lanes without a walk in progress: next camera sample if the path is over, then start the walk
+    if (!walking && !done) {
+      if (!alive) {
+        rng.sample = a.sample_begin + s;
+        ++s;
+        rng.begin(0);
+        R ju = rng.next<R>();
+        R jv = rng.next<R>();
+        R u = rdiv((R)px + ju, (R)(a.width - 1));                  // main.rs:161
+        R v = rdiv((R)(a.height - py - 1) + jv, (R)(a.height - 1));  // main.rs:162-163
+        ray = camera_ray(cam, u, v, rng);
+        thr = Vec3<R>(1, 1, 1);
+        L = Vec3<R>(0, 0, 0);
+        depth_left = a.max_depth;
+        slot = 1;
+        alive = true;
+      }
+      rng.begin(slot);
+      cnt.template inc<ST_RAYS>();
+      walking = walk.start(sc, ray);
+    }
+    const uint32_t n_unfinished = (uint32_t)__popcll(__ballot(!done));
+    if (n_unfinished == 0) break;
+    const uint32_t refill_at = (n_unfinished >> RT_REFILL_SHIFT) > 0 ? (n_unfinished >> RT_REFILL_SHIFT) : 1u;
+    // (2) step all walking lanes until enough of them have run out of work
+    while (__popcll(__ballot(walking)) + refill_at > n_unfinished) {
+      if (walking) walking = walk.step(sc, ray, R(0.001), rng, stack, stack_t, (uint32_t)BLOCK, cnt);
+    }
+    // (3) lanes whose walk is over: one vertex of ray_color (main.rs:77-104)
+    if (!walking && !done) {
+      bool cont;
+      if (walk.best == REF_NONE) {  // main.rs:104
+        cnt.template inc<ST_MISSES>();
+        L = L + thr * background;
+        cont = false;
+      } else {
+        cnt.template inc<ST_CLOSEST>();
+        HitRec<R> h;
+        make_hit_record(sc, walk.best, ray, walk.closest, false, h);
+        const Material<R> mat = sc.materials[h.material];
+        cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
+      }
+      ++slot;
+      --depth_left;
+      if (depth_left == 0) cont = false;
+      if (cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
+      if (!cont) {
+        const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
+        if (!fin) ++nonfinite;
+        if (fin) acc = acc + L;
+        alive = false;
+        if (s == s_end) done = true;
+      }
+    }
+  }
+  if (px < a.width && py < a.height) {
     R* out = accum + 3ull * pixel;
     if (a.splits > 1) {
       atomicAdd(out + 0, acc.x);

@@ -1,4 +1,6 @@
 // Included by rt_f32.hip and rt_f64.hip with RT_SUFFIX / RT_REAL / RT_EARLY_EXIT defined.
+#include <cstdlib>
+
 #include "device/kernels.hpp"
 #include "launch.hpp"
 
@@ -36,6 +38,14 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   }
   if (shape.trav == TRAV_ORDERED) {
     const size_t lds2 = 2 * lds;  // refs + entry distances
+    static const bool no_refill = getenv("RT_ORDERED_NO_REFILL") != nullptr;
+    if (!no_refill) {
+      if (stats)
+        hipLaunchKernelGGL((render_refill_kernel<true>), grid, block, lds2, st, sc, cam, a, accum, dstats);
+      else
+        hipLaunchKernelGGL((render_refill_kernel<false>), grid, block, lds2, st, sc, cam, a, accum, dstats);
+      return hipGetLastError();
+    }
     if (stats)
       hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_ORDERED>), grid, block, lds2, st, sc, cam,
                          a, accum, dstats);
