@@ -345,12 +345,63 @@ struct OrderedWalk {
         }
       }
     }
+    return pop(stack, stack_t, stride);
+  }
+
+  // next stack entry whose box entry is not beyond the closest hit; false when the stack is empty
+  RT_DEV bool pop(const uint32_t* stack, const float* stack_t, uint32_t stride) {
     for (;;) {
       if (sp == 0) return false;
       --sp;
       cur = stack[sp * stride];
       if (!(stack_t[sp * stride] > closest)) return true;
     }
+  }
+
+  // The same walk in two halves, so that a wave can run its lanes' node steps together and their
+  // (rarer, costlier) leaf tests together: node_step needs `cur` to be an inner node, leaf_step a leaf.
+  template <bool STATS>
+  RT_DEV bool node_step(const SceneView<float>& sc, const RayT<float>& r, float t_min, uint32_t* stack, float* stack_t,
+                        uint32_t stride, Cnt<STATS>& cnt) {
+    const float t_incl = next_up(closest);
+    cnt.template inc<ST_NODES>(2);
+    const Node2 n = sc.nodes2[cur];
+    float l0 = t_min, l1 = t_incl, r0 = t_min, r1 = t_incl;
+    const bool hl = slab_hit(n.lbox, n.lbox + 3, r.o, inv_d, l0, l1);
+    const bool hr = slab_hit(n.rbox, n.rbox + 3, r.o, inv_d, r0, r1);
+    if (hl && hr) {
+      const bool left_first = l0 <= r0;
+      stack[sp * stride] = left_first ? n.right : n.left;
+      stack_t[sp * stride] = left_first ? r0 : l0;
+      ++sp;
+      cur = left_first ? n.left : n.right;
+      return true;
+    }
+    if (hl || hr) {
+      cur = hl ? n.left : n.right;
+      return true;
+    }
+    return pop(stack, stack_t, stride);
+  }
+  template <bool STATS>
+  RT_DEV bool leaf_step(const SceneView<float>& sc, const RayT<float>& r, float t_min, Rng& rng, const uint32_t* stack,
+                        const float* stack_t, uint32_t stride, Cnt<STATS>& cnt) {
+    const float t_incl = next_up(closest);
+    float t;
+    bool h;
+    if (ref_kind(cur) == LEAF_COMPLEX)
+      h = complex_t(sc, ref_index(cur), r, t_min, t_incl, rng, t, cnt);
+    else
+      h = prim_t(sc, cur, r, inv_d, a, t_min, t_incl, t, cnt);
+    if (h) {
+      bool take = t < closest;
+      if (t == closest && best != REF_NONE) take = leaf_rank(sc, cur) < leaf_rank(sc, best);
+      if (take) {
+        closest = t;
+        best = cur;
+      }
+    }
+    return pop(stack, stack_t, stride);
   }
 };
 

@@ -334,6 +334,8 @@ struct RenderArgs {
   uint32_t accumulate;  // add to accum instead of overwriting it (ignored when splits > 1: always atomic add)
   uint32_t splits;      // gridDim.y: each block row renders a slice of the launch's samples
   uint32_t stack_depth; // LDS traversal-stack entries per lane
+  uint32_t refill_eighths;  // render_refill_kernel: refill when this many eighths of the unfinished lanes idle (1..8)
+  uint32_t pad;
   uint64_t seed;
 };
 
@@ -499,13 +501,13 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
 // In a BVH-bound scene the number of walk steps per ray is heavy-tailed (1M spheres: mean ~170,
 // tail in the thousands), so a wave that walks "until its slowest lane is done" idles most lanes
 // most of the time (measured: 9 % VALU lane utilisation).  Here the walk is a per-lane state
-// machine (OrderedWalk): all lanes step together, and as soon as a quarter of the wave's unfinished
-// lanes have no ray left to walk, the wave leaves the step loop, shades exactly those lanes (hit
+// machine (OrderedWalk): all lanes step together, and as soon as a set fraction (RenderArgs::refill_eighths) of the wave's
+// unfinished lanes have no ray left to walk, the wave leaves the step loop, shades exactly those lanes (hit
 // record, Material::scatter, next ray or next camera sample) and re-enters the loop with them
 // refilled — the lanes still walking keep their state in registers and their stack in LDS.  Same
 // paths, same draws as render_kernel: a lane's vertices are still processed in order.
-#ifndef RT_REFILL_SHIFT
-#define RT_REFILL_SHIFT 2  // refill when idle lanes >= unfinished lanes >> RT_REFILL_SHIFT
+#ifndef RT_LEAF_SHIFT
+#define RT_LEAF_SHIFT 2  // run the leaf tests once (walking lanes >> RT_LEAF_SHIFT) lanes wait at a leaf
 #endif
 template <bool STATS>
 __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_refill_kernel(SceneView<float> sc, CameraView<float> cam,
@@ -573,10 +575,26 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_refill_kern
     }
     const uint32_t n_unfinished = (uint32_t)__popcll(__ballot(!done));
     if (n_unfinished == 0) break;
-    const uint32_t refill_at = (n_unfinished >> RT_REFILL_SHIFT) > 0 ? (n_unfinished >> RT_REFILL_SHIFT) : 1u;
+    // refill once this many of the unfinished lanes are idle (a.refill_eighths / 8 of them, at least one)
+    const uint32_t refill_q = (n_unfinished * a.refill_eighths) >> 3;
+    const uint32_t refill_at = refill_q > 0 ? refill_q : 1u;
     // (2) step all walking lanes until enough of them have run out of work
-    while (__popcll(__ballot(walking)) + refill_at > n_unfinished) {
-      if (walking) walking = walk.step(sc, ray, R(0.001), rng, stack, stack_t, (uint32_t)BLOCK, cnt);
+    //     node steps run together until a quarter of the walking lanes sit at a leaf, then those
+    //     leaf tests run together (a wave that interleaves them runs the costly leaf code for one
+    //     or two lanes in most iterations)
+    for (;;) {
+      const uint32_t n_walking = (uint32_t)__popcll(__ballot(walking));
+      if (n_walking + refill_at <= n_unfinished) break;
+      const uint32_t leaves_at = (n_walking >> RT_LEAF_SHIFT) > 0 ? (n_walking >> RT_LEAF_SHIFT) : 1u;
+      for (;;) {
+        const bool at_node = walking && !(walk.cur & REF_LEAF);
+        const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node));
+        const uint32_t n_walk_now = (uint32_t)__popcll(__ballot(walking));
+        if (n_node == 0 || n_walk_now - n_node >= leaves_at || n_walk_now + refill_at <= n_unfinished) break;
+        if (at_node) walking = walk.node_step(sc, ray, R(0.001), stack, stack_t, (uint32_t)BLOCK, cnt);
+      }
+      if (walking && (walk.cur & REF_LEAF))
+        walking = walk.leaf_step(sc, ray, R(0.001), rng, stack, stack_t, (uint32_t)BLOCK, cnt);
     }
     // (3) lanes whose walk is over: one vertex of ray_color (main.rs:77-104)
     if (!walking && !done) {

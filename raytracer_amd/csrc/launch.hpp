@@ -14,6 +14,7 @@ struct LaunchShape {
   uint32_t tiles;        // 16x16 pixel tiles = workgroups along grid.x
   uint32_t splits;       // sample splits along grid.y (atomic accumulation when > 1)
   uint32_t stack_depth;  // LDS traversal-stack entries per lane
+  uint32_t refill_eighths = 2;  // ordered walk: see RenderArgs::refill_eighths
   int trav;              // 0 reference-order BVH walk, 1 leaf list, 2 ordered BVH walk (f32 only for 1, 2)
 };
 

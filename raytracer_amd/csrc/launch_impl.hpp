@@ -26,6 +26,8 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   dim3 grid(shape.tiles, shape.splits, 1), block(BLOCK, 1, 1);
   size_t lds = (size_t)shape.stack_depth * BLOCK * sizeof(uint32_t);
   a.stack_depth = shape.stack_depth;
+  a.refill_eighths = shape.refill_eighths;
+  a.pad = 0;
 #if RT_HAS_LINEAR
   if (shape.trav == TRAV_LINEAR) {
     if (stats)
