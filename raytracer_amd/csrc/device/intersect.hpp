@@ -299,7 +299,7 @@ struct OrderedWalk {
   RT_DEV bool start(const SceneView<float>& sc, const RayT<float>& r) {
     closest = Consts<float>::inf;
     best = REF_NONE;
-    cur = sc.root;
+    cur = sc.root2;
     sp = 0;
     inv_d = inverse3(r.d);
     a = sqrlen(r.d);

@@ -18,6 +18,14 @@ constexpr int BLOCK = 256;
 #ifndef RT_RENDER_MIN_WAVES
 #define RT_RENDER_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
 #endif
+// measured on MI355X: the leaf-list kernel (91 VGPRs at 4) gains 4 % at 6 waves, the refill kernel 3-5 % at 5
+// and loses at 6 (spills); the reference-order and f64 kernels stay at 4
+#ifndef RT_LINEAR_MIN_WAVES
+#define RT_LINEAR_MIN_WAVES 6
+#endif
+#ifndef RT_REFILL_MIN_WAVES
+#define RT_REFILL_MIN_WAVES 5
+#endif
 
 // ---- texture.rs:33-69 ---------------------------------------------------------------------
 template <typename R>
@@ -345,7 +353,7 @@ struct RenderArgs {
 constexpr int TRAV_REFERENCE = 0, TRAV_LINEAR = 1, TRAV_ORDERED = 2;
 
 template <typename R, bool STATS, bool EARLY_EXIT, int TRAV>
-__global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
+__global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : RT_RENDER_MIN_WAVES) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
                                                        R* __restrict__ accum, DeviceStats* stats) {
   constexpr bool LINEAR = TRAV == TRAV_LINEAR;
   extern __shared__ uint32_t lds_stack[];
@@ -510,7 +518,7 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_kernel(Scen
 #define RT_LEAF_SHIFT 2  // run the leaf tests once (walking lanes >> RT_LEAF_SHIFT) lanes wait at a leaf
 #endif
 template <bool STATS>
-__global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_refill_kernel(SceneView<float> sc, CameraView<float> cam,
+__global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kernel(SceneView<float> sc, CameraView<float> cam,
                                                                                  RenderArgs a, float* __restrict__ accum,
                                                                                  DeviceStats* stats) {
   using R = float;
@@ -551,7 +559,12 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_refill_kern
   walk.closest = 0.0f;
   walk.a = 0.0f;
 
+#ifdef RT_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
   for (;;) {
+    RT_STAMP(0);
     // (1) lanes without a walk in progress: next camera sample if the path is over, then start the walk
     if (!walking && !done) {
       if (!alive) {
@@ -573,6 +586,7 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_refill_kern
       cnt.template inc<ST_RAYS>();
       walking = walk.start(sc, ray);
     }
+    RT_STAMP(1);
     const uint32_t n_unfinished = (uint32_t)__popcll(__ballot(!done));
     if (n_unfinished == 0) break;
     // refill once this many of the unfinished lanes are idle (a.refill_eighths / 8 of them, at least one)
@@ -586,6 +600,7 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_refill_kern
       const uint32_t n_walking = (uint32_t)__popcll(__ballot(walking));
       if (n_walking + refill_at <= n_unfinished) break;
       const uint32_t leaves_at = (n_walking >> RT_LEAF_SHIFT) > 0 ? (n_walking >> RT_LEAF_SHIFT) : 1u;
+      RT_STAMP(2);
       for (;;) {
         const bool at_node = walking && !(walk.cur & REF_LEAF);
         const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node));
@@ -593,9 +608,12 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_refill_kern
         if (n_node == 0 || n_walk_now - n_node >= leaves_at || n_walk_now + refill_at <= n_unfinished) break;
         if (at_node) walking = walk.node_step(sc, ray, R(0.001), stack, stack_t, (uint32_t)BLOCK, cnt);
       }
+      RT_STAMP(3);
       if (walking && (walk.cur & REF_LEAF))
         walking = walk.leaf_step(sc, ray, R(0.001), rng, stack, stack_t, (uint32_t)BLOCK, cnt);
+      RT_STAMP(4);
     }
+    RT_STAMP(5);
     // (3) lanes whose walk is over: one vertex of ray_color (main.rs:77-104)
     if (!walking && !done) {
       bool cont;
@@ -622,7 +640,12 @@ __global__ void __launch_bounds__(BLOCK, RT_RENDER_MIN_WAVES) render_refill_kern
         if (s == s_end) done = true;
       }
     }
+    RT_STAMP(6);
   }
+#ifdef RT_STAMPS
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&stats->stamp[i], stamp_acc[i]);
+#endif
   if (px < a.width && py < a.height) {
     R* out = accum + 3ull * pixel;
     if (a.splits > 1) {

@@ -53,8 +53,7 @@ struct Attr {  // cold per-primitive attributes
   uint32_t pad;
 };
 // Node of the ORDERED walk (f32): the boxes of BOTH children next to their references, so one
-// 64-byte fetch decides which child is nearer.  flags bit 0 / 1: the left / right child is a leaf
-// whose box is only an ordering hint, not a proven bound (never cull by it).
+// 64-byte fetch decides which child is nearer.
 struct alignas(64) Node2 {
   float lbox[6];
   float rbox[6];
@@ -123,6 +122,7 @@ template <typename R> struct SceneView {
   uint32_t n_linear;           // 0 = scene not eligible for the leaf-list path
   uint32_t linear_has_media;   // some leaf record carries LINF_MEDIUM
   uint32_t root;
+  uint32_t root2;  // root of nodes2 (REF_NONE if the ordered walk is not available)
   uint32_t lights_kind, n_lights;
   R background[3];
 };

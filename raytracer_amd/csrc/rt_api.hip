@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/rt.h"
+#include "accel_build.hpp"
 #include "launch.hpp"
 
 using namespace rt;
@@ -94,6 +95,8 @@ struct DeviceBuffers {
   }
 };
 
+constexpr uint32_t MAX_STACK_DEPTH = 64;
+
 // What rt_scene_create learns from one left-first DFS of the tree.
 struct TreeFacts {
   std::vector<uint32_t> rank_sphere, rank_msphere, rank_cube, rank_complex;  // DFS rank per leaf
@@ -107,6 +110,7 @@ struct TreeFacts {
 template <typename R> struct SceneSide {
   DeviceBuffers bufs;
   SceneView<R> view{};
+  uint32_t ordered_root = RT_REF_NONE, ordered_height = 0;  // the ordered walk's tree (f32 side), if built
 };
 
 template <typename R>
@@ -122,10 +126,19 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
     nodes[i].left = d.node_left[i];
     nodes[i].right = d.node_right[i];
   }
-  // ordered-walk nodes (f32): both children's boxes beside their references
+  // ordered-walk tree (f32): its own binned-SAH tree over the same leaves (accel_build.hpp); the
+  // reference's tree above stays what the reference-order walk and parity level 1 use.  Each Node2
+  // holds both children's boxes beside their references.  RT_ORDERED_REFERENCE_TREE=1 (A/B) mirrors
+  // the reference's tree into Node2 form instead.
   std::vector<Node2> nodes2;
   if constexpr (sizeof(R) == 4) {
-    if (facts.conservative) {
+    const bool own_tree = getenv("RT_ORDERED_REFERENCE_TREE") == nullptr;
+    if (facts.conservative && facts.leaf_refs.size() >= 2 && own_tree) {
+      const uint32_t n_leaves = (uint32_t)facts.leaf_refs.size();
+      nodes2 = accel::build_sah(facts.leaf_box.data(), facts.leaf_refs.data(), n_leaves,
+                                std::min(MAX_STACK_DEPTH, accel::ceil_log2(n_leaves) + 6u), &s.ordered_height);
+      s.ordered_root = 0;
+    } else if (facts.conservative && d.n_nodes > 0 && !(d.root & RT_REF_LEAF) && d.root != RT_REF_NONE) {
       nodes2.resize(d.n_nodes);
       auto child_box = [&](uint32_t ref, float* out) {
         if (ref & RT_REF_LEAF) {
@@ -146,8 +159,9 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
         child_box(d.node_right[i], nodes2[i].rbox);
         nodes2[i].left = d.node_left[i];
         nodes2[i].right = d.node_right[i];
-        nodes2[i].flags = 0;  // with verified-conservative boxes every leaf box may cull
       }
+      s.ordered_root = d.root;
+      s.ordered_height = accel::height_of(nodes2, d.root);
     }
   }
   std::vector<Real4<R>> spheres(d.n_spheres);
@@ -350,6 +364,7 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
   for (size_t k = 0; k < linear_rec.size() / LIN_DWORDS; ++k)
     if (linear_rec[k * LIN_DWORDS + LIN_FLAGS] & LINF_MEDIUM) s.view.linear_has_media = 1;
   s.view.root = d.root;
+  s.view.root2 = s.ordered_root;
   s.view.lights_kind = d.lights_kind;
   s.view.n_lights = d.n_lights;
   for (int k = 0; k < 3; ++k) s.view.background[k] = conv<R>(d.background[k]);
@@ -454,7 +469,6 @@ bool leaf_world_bounds(const rt_scene_desc& d, const std::vector<Complex>& compl
   return true;
 }
 
-constexpr uint32_t MAX_STACK_DEPTH = 64;
 constexpr uint32_t TARGET_WAVES = 256u * 16u;  // enough waves to fill 256 CUs at 4 waves/SIMD
 
 }  // namespace
@@ -716,10 +730,10 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   LaunchShape sh;
   sh.trav = 0;  // the reference's left-first walk: always valid
   if (f32_fast && s->boxes_conservative && cam && cam->time_open >= s->safe_t_lo && cam->time_close <= s->safe_t_hi)
-    sh.trav = s->f32.view.n_linear > 0 ? 1 : (s->f32.view.root != RT_REF_NONE && !(s->f32.view.root & RT_REF_LEAF) ? 2 : 0);
+    sh.trav = s->f32.view.n_linear > 0 ? 1 : (s->f32.ordered_root != RT_REF_NONE ? 2 : 0);
   uint32_t tx = (w + 15) / 16, ty = (h + 15) / 16;
   sh.tiles = tx * ty;
-  sh.stack_depth = s->stack_depth;
+  sh.stack_depth = sh.trav == 2 ? std::max(s->f32.ordered_height, 1u) : s->stack_depth;
   // ordered walk: the longer a scene's walks, the smaller the idle fraction worth interrupting them for
   // (measured optimum: 5/8 at ~500-1500 nodes, 3/8 at 20 k, 2/8 at 1 M)
   static const char* re = getenv("RT_REFILL_EIGHTHS");  // tuning override
