@@ -290,6 +290,11 @@ RT_DEV float next_up(float x) {  // smallest float above a positive finite x; +i
 // a time and hands lanes whose walk has finished a new ray while the others keep walking (their
 // state stays in registers, their stack in LDS).
 struct OrderedWalk {
+  // A pending entry's box-entry distance is kept in 16 bits (the float's upper half, i.e. rounded
+  // toward zero: never above the true distance, so culling by it stays conservative); with the 32-bit
+  // reference that is 6 B of LDS per stack level and lane instead of 8.
+  static RT_DEV uint16_t entry_bits(float t) { return (uint16_t)(__float_as_uint(t) >> 16); }
+  static RT_DEV float entry_float(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
   uint32_t cur, sp, best;
   float closest;
   Vec3<float> inv_d;
@@ -309,7 +314,7 @@ struct OrderedWalk {
   // one node (both child boxes) or one leaf test, then the next entry; false when the walk is over
   template <bool STATS>
   RT_DEV bool step(const SceneView<float>& sc, const RayT<float>& r, float t_min, Rng& rng, uint32_t* stack,
-                   float* stack_t, uint32_t stride, Cnt<STATS>& cnt) {
+                   uint16_t* stack_t, uint32_t stride, Cnt<STATS>& cnt) {
     const float t_incl = next_up(closest);
     if (!(cur & REF_LEAF)) {
       cnt.template inc<ST_NODES>(2);
@@ -320,7 +325,7 @@ struct OrderedWalk {
       if (hl && hr) {
         const bool left_first = l0 <= r0;
         stack[sp * stride] = left_first ? n.right : n.left;
-        stack_t[sp * stride] = left_first ? r0 : l0;
+        stack_t[sp * stride] = entry_bits(left_first ? r0 : l0);
         ++sp;
         cur = left_first ? n.left : n.right;
         return true;
@@ -349,19 +354,19 @@ struct OrderedWalk {
   }
 
   // next stack entry whose box entry is not beyond the closest hit; false when the stack is empty
-  RT_DEV bool pop(const uint32_t* stack, const float* stack_t, uint32_t stride) {
+  RT_DEV bool pop(const uint32_t* stack, const uint16_t* stack_t, uint32_t stride) {
     for (;;) {
       if (sp == 0) return false;
       --sp;
       cur = stack[sp * stride];
-      if (!(stack_t[sp * stride] > closest)) return true;
+      if (!(entry_float(stack_t[sp * stride]) > closest)) return true;
     }
   }
 
   // The same walk in two halves, so that a wave can run its lanes' node steps together and their
   // (rarer, costlier) leaf tests together: node_step needs `cur` to be an inner node, leaf_step a leaf.
   template <bool STATS>
-  RT_DEV bool node_step(const SceneView<float>& sc, const RayT<float>& r, float t_min, uint32_t* stack, float* stack_t,
+  RT_DEV bool node_step(const SceneView<float>& sc, const RayT<float>& r, float t_min, uint32_t* stack, uint16_t* stack_t,
                         uint32_t stride, Cnt<STATS>& cnt) {
     const float t_incl = next_up(closest);
     cnt.template inc<ST_NODES>(2);
@@ -372,7 +377,7 @@ struct OrderedWalk {
     if (hl && hr) {
       const bool left_first = l0 <= r0;
       stack[sp * stride] = left_first ? n.right : n.left;
-      stack_t[sp * stride] = left_first ? r0 : l0;
+      stack_t[sp * stride] = entry_bits(left_first ? r0 : l0);
       ++sp;
       cur = left_first ? n.left : n.right;
       return true;
@@ -385,7 +390,7 @@ struct OrderedWalk {
   }
   template <bool STATS>
   RT_DEV bool leaf_step(const SceneView<float>& sc, const RayT<float>& r, float t_min, Rng& rng, const uint32_t* stack,
-                        const float* stack_t, uint32_t stride, Cnt<STATS>& cnt) {
+                        const uint16_t* stack_t, uint32_t stride, Cnt<STATS>& cnt) {
     const float t_incl = next_up(closest);
     float t;
     bool h;

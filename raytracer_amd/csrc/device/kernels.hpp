@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : RT_RE
         OrderedWalk walk;
         bool more = walk.start(sc, ray);
         while (more)
-          more = walk.step(sc, ray, R(0.001), rng, stack, reinterpret_cast<float*>(stack + a.stack_depth * BLOCK),
+          more = walk.step(sc, ray, R(0.001), rng, stack, reinterpret_cast<uint16_t*>(lds_stack + a.stack_depth * BLOCK) + threadIdx.x,
                            (uint32_t)BLOCK, cnt);
         t = walk.closest;
         best = walk.best;
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
   using R = float;
   extern __shared__ uint32_t lds_stack[];
   uint32_t* stack = lds_stack + threadIdx.x;
-  float* stack_t = reinterpret_cast<float*>(stack + a.stack_depth * BLOCK);
+  uint16_t* stack_t = reinterpret_cast<uint16_t*>(lds_stack + a.stack_depth * BLOCK) + threadIdx.x;
   __shared__ Light<R> s_lights[LDS_MAX_LIGHTS];
   {
     const uint32_t n_l = sc.n_lights < LDS_MAX_LIGHTS ? sc.n_lights : LDS_MAX_LIGHTS;

@@ -39,7 +39,7 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
     return hipGetLastError();
   }
   if (shape.trav == TRAV_ORDERED) {
-    const size_t lds2 = 2 * lds;  // refs + entry distances
+    const size_t lds2 = lds + lds / 2;  // 32-bit refs + 16-bit entry distances
     static const bool no_refill = getenv("RT_ORDERED_NO_REFILL") != nullptr;
     if (!no_refill) {
       if (stats)
