@@ -44,18 +44,20 @@ for pmc in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     files = glob.glob(os.path.join(pmc, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         continue
-    acc = defaultdict(float)
-    n = defaultdict(int)
+    acc = defaultdict(lambda: defaultdict(float))
+    n = defaultdict(lambda: defaultdict(int))
     for r in csv.DictReader(open(files[0])):
-        if "render_kernel" not in r["Kernel_Name"]:
+        if "render" not in r["Kernel_Name"]:
             continue
-        acc[r["Counter_Name"]] += float(r["Counter_Value"])
-        n[r["Counter_Name"]] += 1
-    lines += [f"## PMC pass `{os.path.basename(pmc)}` — render_kernel only, summed over its dispatches "
-              f"(`bench.py --steps 1 --warmup 0 --spp 256`)", "", "| counter | sum | dispatches | per dispatch |",
-              "|---|---|---|---|"]
-    for k in sorted(acc):
-        lines.append(f"| {k} | {acc[k]:.6g} | {n[k]} | {acc[k]/max(1,n[k]):.6g} |")
-    lines.append("")
+        kn = r["Kernel_Name"].split("(")[0].replace("void rt::", "")
+        acc[kn][r["Counter_Name"]] += float(r["Counter_Value"])
+        n[kn][r["Counter_Name"]] += 1
+    for kn in sorted(acc):
+        lines += [f"## PMC pass `{os.path.basename(pmc)}` — `{kn}`, summed over its dispatches "
+                  f"(template args: <R, STATS, EARLY_EXIT, TRAV>; STATS=true is bench.py's counted pass)", "",
+                  "| counter | sum | dispatches | per dispatch |", "|---|---|---|---|"]
+        for k in sorted(acc[kn]):
+            lines.append(f"| {k} | {acc[kn][k]:.6g} | {n[kn][k]} | {acc[kn][k]/max(1,n[kn][k]):.6g} |")
+        lines.append("")
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
 print("\n".join(lines))
