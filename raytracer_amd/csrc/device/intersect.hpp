@@ -448,43 +448,39 @@ RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, const RayT<floa
   for (uint32_t k = 0; k < n_linear; ++k) {
     const float* rec = lin + k * LIN_DWORDS;
     const uint32_t flags = __float_as_uint(rec[LIN_FLAGS]);
-    Vec3<float> o = r.o, d = r.d, inv_d = inv_d0;
-    float a = a0;
+    float t;
+    bool h;
+    // one leaf in a given frame; instantiated twice (world frame / the record's rigid map) so the
+    // common world-frame case carries no register copies of the ray
+    auto test = [&](const Vec3<float> o, const Vec3<float> d, const Vec3<float> inv_d, const float a) {
+      if (!MEDIA || !(flags & LINF_MEDIUM)) return lin_prim_t(rec, flags, o, d, inv_d, a, t_min, closest, t, cnt);
+      // hittable.rs:319-349
+      cnt.template inc<ST_MEDIUM>();
+      float t1, t2;
+      cnt.template inc<ST_MEDIUM_PROBES>();
+      if (!lin_prim_t(rec, flags, o, d, inv_d, a, -Consts<float>::inf, Consts<float>::inf, t1, cnt)) return false;
+      cnt.template inc<ST_MEDIUM_PROBES>();
+      if (!lin_prim_t(rec, flags, o, d, inv_d, a, t1 + 0.0001f, Consts<float>::inf, t2, cnt)) return false;
+      t1 = rmax(t1, t_min);
+      t2 = rmin(t2, closest);
+      if (!(t1 < t2)) return false;
+      t1 = rmax(t1, 0.0f);
+      const float ray_length = length(r.d);  // rigid maps keep |d|
+      const float hit_distance = rec[LIN_NID] * rlog(rng.keyed<float>(__float_as_uint(rec[LIN_OBJECT])));
+      if (hit_distance > (t2 - t1) * ray_length) return false;
+      t = t1 + rdiv(hit_distance, ray_length);
+      return true;
+    };
     if (flags & LINF_XF) {  // wave-uniform branch
-      o = xf_point(rec + LIN_M, rec + LIN_B, r.o);
-      d = xf_dir(rec + LIN_M, r.d);
-      inv_d = inverse3(d);
-      a = sqrlen(d);
+      const Vec3<float> o = xf_point(rec + LIN_M, rec + LIN_B, r.o);
+      const Vec3<float> d = xf_dir(rec + LIN_M, r.d);
       if constexpr (STATS) {
         cnt.template inc<ST_ROTATE>(__float_as_uint(rec[LIN_FLAGS]) >> 16 & 0xFF);
         cnt.template inc<ST_TRANSLATE>(__float_as_uint(rec[LIN_FLAGS]) >> 24);
       }
-    }
-    float t;
-    bool h;
-    if (!MEDIA || !(flags & LINF_MEDIUM)) {
-      h = lin_prim_t(rec, flags, o, d, inv_d, a, t_min, closest, t, cnt);
-    } else {  // hittable.rs:319-349
-      cnt.template inc<ST_MEDIUM>();
-      h = false;
-      float t1, t2;
-      cnt.template inc<ST_MEDIUM_PROBES>();
-      if (lin_prim_t(rec, flags, o, d, inv_d, a, -Consts<float>::inf, Consts<float>::inf, t1, cnt)) {
-        cnt.template inc<ST_MEDIUM_PROBES>();
-        if (lin_prim_t(rec, flags, o, d, inv_d, a, t1 + 0.0001f, Consts<float>::inf, t2, cnt)) {
-          t1 = rmax(t1, t_min);
-          t2 = rmin(t2, closest);
-          if (t1 < t2) {
-            t1 = rmax(t1, 0.0f);
-            const float ray_length = length(r.d);  // rigid maps keep |d|
-            const float hit_distance = rec[LIN_NID] * rlog(rng.keyed<float>(__float_as_uint(rec[LIN_OBJECT])));
-            if (!(hit_distance > (t2 - t1) * ray_length)) {
-              t = t1 + rdiv(hit_distance, ray_length);
-              h = true;
-            }
-          }
-        }
-      }
+      h = test(o, d, inverse3(d), sqrlen(d));
+    } else {
+      h = test(r.o, r.d, inv_d0, a0);
     }
     if (h && t < closest) {
       closest = t;
@@ -669,12 +665,14 @@ RT_DEV void lin_hit_record(const SceneView<float>& sc, const float* rec, const R
   } else if (flags & LINF_CUBE) {
     const Vec3<float> pl = o + t * d;
     const Vec3<float> p0(rec[LIN_PRIM], rec[LIN_PRIM + 1], rec[LIN_PRIM + 2]);
-    const Vec3<float> p1(rec[LIN_PRIM + 3], rec[LIN_PRIM + 4], rec[LIN_PRIM + 5]);
-    const Vec3<float> rel = (pl - p0) / (p1 - p0);
+    const Vec3<float> inv_ext(rec[LIN_INVEXT], rec[LIN_INVEXT + 1], rec[LIN_INVEXT + 2]);  // 1 / (p1 - p0)
+    const Vec3<float> rel = (pl - p0) * inv_ext;
     const Vec3<float> n = cube_normal(rel);
-    const float az = rabs(n.z), ax = rabs(n.x), ay = rabs(n.y);
-    h.uv.x = rel.x * az + rel.y * ax + rel.x * ay;
-    h.uv.y = rel.y * az + rel.z * ax + rel.z * ay;
+    if (mat.flags & MATF_NEEDS_UV) {
+      const float az = rabs(n.z), ax = rabs(n.x), ay = rabs(n.y);
+      h.uv.x = rel.x * az + rel.y * ax + rel.x * ay;
+      h.uv.y = rel.y * az + rel.z * ax + rel.z * ay;
+    }
     face_normal(d, n, h);
   } else {
     const Vec3<float> pl = o + t * d;

@@ -89,7 +89,8 @@ template <typename R> struct Material {
 // memory and follow no dependent pointer chain.
 constexpr uint32_t LIN_DWORDS = 48, LIN_MAX_LEAVES = 16, LDS_MAX_LIGHTS = 8;
 constexpr uint32_t LIN_FLAGS = 0, LIN_REF = 1, LIN_NID = 2, LIN_OBJECT = 3, LIN_M = 4, LIN_B = 13, LIN_PRIM = 16,
-                   LIN_MAT = 24;  // Material<float> image: 12 dwords
+                   LIN_MAT = 24,  // Material<float> image: 12 dwords
+                   LIN_INVEXT = 36;  // cube: 1 / (p1 - p0), 3 dwords
 constexpr uint32_t LINF_XF = 1u, LINF_CUBE = 2u, LINF_MEDIUM = 4u;
 template <typename R> struct Texture {
   uint32_t tag, odd, even, width, height, pad;

@@ -342,6 +342,8 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
       if (RT_REF_KIND(body) == RT_LEAF_CUBE) {
         flags |= LINF_CUBE;
         for (int c = 0; c < 6; ++c) put(k, LIN_PRIM + c, (float)d.cube[6 * (size_t)bi + c]);
+        for (int c = 0; c < 3; ++c)
+          put(k, LIN_INVEXT + c, (float)(1.0 / ((double)(float)d.cube[6 * (size_t)bi + 3 + c] - (double)(float)d.cube[6 * (size_t)bi + c])));
         if (!(flags & LINF_MEDIUM)) material = d.cube_material[bi];
         if (RT_REF_KIND(ref) != RT_LEAF_COMPLEX) object = d.cube_object[bi];
       } else {
