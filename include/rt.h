@@ -231,6 +231,16 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* par
 int rt_render_multi(int n_dev, const int* devices, const rt_scene_desc* desc, const rt_camera* cam,
                     const rt_params* params, float* accum_rgb, rt_stats* per_dev);
 
+/* No counterpart in the reference (its only tree is new_bvh, hittable.rs:159-206, which the host
+ * layer builds): the binned-SAH tree the f32 fast path walks near-child-first on large scenes
+ * (DESIGN.md section 3.2), exposed so that it can be checked without a GPU.  Host only.
+ * leaf_box: [n_leaves][6] f32 (lo xyz, hi xyz); leaf_refs: [n_leaves] opaque leaf references with
+ * RT_REF_LEAF set; nodes_out: [n_leaves - 1] nodes of 16 dwords each: left box lo/hi (6 f32), right
+ * box lo/hi (6 f32), left ref, right ref, 2 reserved; node 0 is the root, children follow parents
+ * (pre-order).  max_depth caps the height (raised to ceil(log2 n) if smaller).              */
+int rt_debug_build_tree(uint32_t n_leaves, const float* leaf_box, const uint32_t* leaf_refs, uint32_t max_depth,
+                        uint32_t* nodes_out, uint32_t* height_out);
+
 /* Replaces: `pixel_color /= spp; pixel_from_color(pixel_color)` (main.rs:167-168, 51-63):
  * gamma 2, clamp [0, 0.9999], ×256, truncate; NaN → 0 like Rust's saturating `as u8`.    */
 void rt_tonemap(const float* accum_rgb, uint64_t n_pixels, uint64_t spp, uint8_t* rgb8);

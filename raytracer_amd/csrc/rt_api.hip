@@ -992,6 +992,18 @@ int rt_render_multi(int n_dev, const int* devices, const rt_scene_desc* desc, co
   return rc;
 }
 
+int rt_debug_build_tree(uint32_t n_leaves, const float* leaf_box, const uint32_t* leaf_refs, uint32_t max_depth,
+                        uint32_t* nodes_out, uint32_t* height_out) {
+  if (n_leaves < 2 || !leaf_box || !leaf_refs || !nodes_out || !height_out)
+    return fail(RT_ERR_BAD_ARG, "rt_debug_build_tree: need >= 2 leaves and non-null arrays");
+  for (uint32_t i = 0; i < n_leaves; ++i)
+    if (!(leaf_refs[i] & RT_REF_LEAF)) return fail(RT_ERR_BAD_ARG, "rt_debug_build_tree: leaf_refs[%u] lacks RT_REF_LEAF", i);
+  static_assert(sizeof(Node2) == 64, "Node2 is one 64-byte line");
+  std::vector<Node2> nodes = accel::build_sah(leaf_box, leaf_refs, n_leaves, max_depth, height_out);
+  std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(Node2));
+  return RT_OK;
+}
+
 void rt_tonemap(const float* accum, uint64_t n_pixels, uint64_t spp, uint8_t* rgb8) {
   if (!accum || !rgb8) return;
   const float inv = 1.0f / (float)spp;
