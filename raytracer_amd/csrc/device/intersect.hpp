@@ -374,18 +374,14 @@ struct OrderedWalk {
     float l0 = t_min, l1 = t_incl, r0 = t_min, r1 = t_incl;
     const bool hl = slab_hit(n.lbox, n.lbox + 3, r.o, inv_d, l0, l1);
     const bool hr = slab_hit(n.rbox, n.rbox + 3, r.o, inv_d, r0, r1);
-    if (hl && hr) {
-      const bool left_first = l0 <= r0;
-      stack[sp * stride] = left_first ? n.right : n.left;
-      stack_t[sp * stride] = entry_bits(left_first ? r0 : l0);
-      ++sp;
-      cur = left_first ? n.left : n.right;
-      return true;
-    }
-    if (hl || hr) {
-      cur = hl ? n.left : n.right;
-      return true;
-    }
+    // select-only bookkeeping (one divergent region, the pop): the far child is written to the free
+    // slot `sp` whether or not it is kept (a node at level L has sp <= L - 1 < height: in bounds)
+    const bool left_first = hl && (!hr || l0 <= r0);
+    stack[sp * stride] = left_first ? n.right : n.left;
+    stack_t[sp * stride] = entry_bits(left_first ? r0 : l0);
+    sp += (hl && hr) ? 1u : 0u;
+    cur = left_first ? n.left : n.right;
+    if (hl || hr) return true;
     return pop(stack, stack_t, stride);
   }
   template <bool STATS>
