@@ -224,7 +224,11 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
   }
   Vec3<R> direction(1, 0, 0);
   if (!no_sample) {
-    const ONB<R> uvw = ONB<R>::from_w(axis);
+    // f32: the hit normal is unit length already (cube faces, (p-c)/r, rigid maps of those); only the
+    // axis towards a light needs normalising
+    if constexpr (sizeof(R) == 4)
+      if (from_light) axis = normalize(axis);
+    const ONB<R> uvw = sizeof(R) == 4 ? ONB<R>::from_unit_w(axis) : ONB<R>::from_w(axis);
     const R r1 = rng.next<R>();
     const R r2 = rng.next<R>();
     R z, radial;
@@ -239,9 +243,11 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
     sincos_2pi(r1, sn, cs);
     direction = uvw.local(Vec3<R>(cs * radial, sn * radial, z));
   }
-  const Vec3<R> cos_w = normalize(h.normal);  // = ONB::from_w(hit.normal).w of PDF::Cosine
-  // pdf.rs:13-31
-  Vec3<R> unit = normalize(direction);
+  // cos_w = ONB::from_w(hit.normal).w of PDF::Cosine; unit = normalize(direction) (pdf.rs:13-31).  In f32
+  // both are unit already to rounding: the normal as above, the direction as an orthonormal basis
+  // applied to (cos phi * radial, sin phi * radial, z) with radial^2 + z^2 = 1.
+  const Vec3<R> cos_w = sizeof(R) == 4 ? h.normal : normalize(h.normal);
+  Vec3<R> unit = sizeof(R) == 4 ? direction : normalize(direction);
   R cosine = dot(unit, cos_w);
   R cos_pdf = cosine <= R(0) ? R(0) : rdiv(cosine, Consts<R>::pi);
   R pdf_value;

@@ -144,6 +144,16 @@ template <typename R> struct ONB {
     o.u = cross(o.w, o.v);
     return o;
   }
+  // Same basis for a w that is already unit length (f32 kernels: hit normals, which the reference
+  // normalises again); cross(w, a) written out for the two axis choices.
+  RT_DEV static ONB from_unit_w(Vec3<R> w) {
+    ONB o;
+    o.w = w;
+    const bool big = rabs(w.x) > R(0.9);
+    o.v = normalize(big ? Vec3<R>(-w.z, R(0), w.x) : Vec3<R>(R(0), w.z, -w.y));
+    o.u = cross(o.w, o.v);
+    return o;
+  }
   RT_DEV Vec3<R> local(Vec3<R> a) const { return u * a.x + v * a.y + w * a.z; }
 };
 
