@@ -166,6 +166,20 @@ template <typename R> RT_DEV Vec3<R> xf_dir_transposed(const R* m, Vec3<R> v) {
           m[2] * v.x + m[5] * v.y + m[8] * v.z};
 }
 
+// hittable.rs:331: the medium's second boundary probe starts at hit1.t + 0.0001.  In f32 that sum
+// rounds back to hit1.t once |hit1.t| >= 2048 (a ray deep inside a large medium: the entry lies far
+// behind the origin), the probe would find the entry again and the medium would never scatter; the
+// f32 kernels therefore start the probe at least one float above hit1.t.
+template <typename R> RT_DEV R second_probe_start(R t1) {
+  const R t = t1 + R(0.0001);
+  if constexpr (sizeof(R) == 4) {
+    const uint32_t b = __float_as_uint(t1);
+    const float up = t1 > 0.0f ? __uint_as_float(b + 1u) : (t1 < 0.0f ? __uint_as_float(b - 1u) : 1e-45f);
+    return t > up ? t : up;
+  }
+  return t;
+}
+
 // A chain of Translate / Rotate / ConstantMedium wrappers around one primitive
 // (hittable.rs:319-386).  All wrappers are rigid, so t is the same in every frame.
 template <typename R, bool STATS>
@@ -210,7 +224,7 @@ RT_DEV bool complex_t(const SceneView<R>& sc, uint32_t idx, const RayT<R>& r, R 
   cnt.template inc<ST_MEDIUM_PROBES>();
   if (!prim_t(sc, cx.body, lr, inv_d, a, -Consts<R>::inf, Consts<R>::inf, t1, cnt)) return false;
   cnt.template inc<ST_MEDIUM_PROBES>();
-  if (!prim_t(sc, cx.body, lr, inv_d, a, t1 + R(0.0001), Consts<R>::inf, t2, cnt)) return false;
+  if (!prim_t(sc, cx.body, lr, inv_d, a, second_probe_start(t1), Consts<R>::inf, t2, cnt)) return false;
   t1 = rmax(t1, t_min);
   t2 = rmin(t2, t_max);
   if (t1 >= t2) return false;
@@ -456,7 +470,7 @@ RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, const RayT<floa
       cnt.template inc<ST_MEDIUM_PROBES>();
       if (!lin_prim_t(rec, flags, o, d, inv_d, a, -Consts<float>::inf, Consts<float>::inf, t1, cnt)) return false;
       cnt.template inc<ST_MEDIUM_PROBES>();
-      if (!lin_prim_t(rec, flags, o, d, inv_d, a, t1 + 0.0001f, Consts<float>::inf, t2, cnt)) return false;
+      if (!lin_prim_t(rec, flags, o, d, inv_d, a, second_probe_start(t1), Consts<float>::inf, t2, cnt)) return false;
       t1 = rmax(t1, t_min);
       t2 = rmin(t2, closest);
       if (!(t1 < t2)) return false;

@@ -92,7 +92,8 @@ def _psnr(a, b):
     return 10 * np.log10(1.0 / mse) if mse > 0 else np.inf
 
 
-@pytest.mark.parametrize("name", ["random_scene", "simple_light", "cornell_box", "earth", "small_scene"])
+@pytest.mark.parametrize("name", ["random_scene", "simple_light", "cornell_box", "earth", "small_scene", "final_scene",
+                                  "bvh_stress"])
 def test_render_f32_within_monte_carlo_noise(name, earthmap):
     """f32 production kernel vs oracle, different seeds, matched spp: the difference of two
     independent estimates must look like noise of the measured per-pixel variance."""
@@ -108,7 +109,10 @@ def test_render_f32_within_monte_carlo_noise(name, earthmap):
     # oracle-vs-oracle difference estimates the noise floor; gpu-vs-oracle must not exceed it by much
     d_ref = np.sqrt(np.mean((np.clip(o1, 0, 1) - np.clip(o2, 0, 1))[fin] ** 2))
     d_gpu = np.sqrt(np.mean((np.clip(g, 0, 1) - np.clip(o1, 0, 1))[fin] ** 2))
-    mean_ratio = g[fin].mean() / o1[fin].mean()
+    if name in ("final_scene", "bvh_stress"):  # heavy-tailed estimators (fireflies of 1e20 and more): compare clipped means
+        mean_ratio = np.clip(g, 0, 1)[fin].mean() / np.clip(o1, 0, 1)[fin].mean()
+    else:
+        mean_ratio = g[fin].mean() / o1[fin].mean()
     print(f"{name}: rmse gpu-vs-oracle {d_gpu:.4g}, oracle-vs-oracle {d_ref:.4g}, mean ratio {mean_ratio:.4f}, "
           f"nonfinite samples {gst['nonfinite_samples']}")
     assert d_gpu <= 1.25 * d_ref + 1e-4
