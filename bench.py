@@ -75,10 +75,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # RT_BENCH_REHEARSAL=1: rehearse the multi-rank path on a ONE-GPU box (every rank on device 0, gloo
+    # instead of RCCL, which refuses two ranks on one device).  Not a measurement.
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     width = args.width
     height = R.image_height(width, args.aspect)
@@ -146,7 +154,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
             "config": {"workload": f"{args.scene} {width}x{height}, {args.spp} spp per GPU, max depth {args.max_depth}"
                                    + (f", n={args.n}" if args.n else ""),
                        "scene_seed": 5, "bvh_seed": 7, "render_seed": 1,
