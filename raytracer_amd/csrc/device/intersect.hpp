@@ -237,6 +237,101 @@ RT_DEV bool complex_t(const SceneView<R>& sc, uint32_t idx, const RayT<R>& r, R 
   return true;
 }
 
+// f32, any leaf, ONE copy of each primitive's code: a wave whose lanes sit at leaves of different
+// kinds (bare sphere, moving sphere, wrapped sphere, medium around a sphere ...) runs the sphere test
+// once for all of them instead of once per kind (prim_t inlined under complex_t and under the medium's
+// probes).  Same arithmetic as prim_t / complex_t<float>.
+template <bool STATS>
+RT_DEV bool leaf_t_unified(const SceneView<float>& sc, uint32_t ref, const RayT<float>& r, Vec3<float> inv_d, float a,
+                           float t_min, float t_max, Rng& rng, float& t_out, Cnt<STATS>& cnt) {
+  uint32_t kind = ref_kind(ref), idx = ref_index(ref);
+  Vec3<float> o = r.o, d = r.d;
+  bool medium = false;
+  float neg_inv_density = 0.0f;
+  uint32_t object = 0;
+  if (kind == LEAF_COMPLEX) {
+    const Complex cx = sc.complexes[idx];
+    const ComplexXf<float>& xf = sc.complex_xf[idx];
+    cnt.template inc<ST_TRANSLATE>(cx.n_translate);
+    cnt.template inc<ST_ROTATE>(cx.n_rotate);
+    o = xf_point(xf.m_full, xf.b_full, r.o);
+    d = xf_dir(xf.m_full, r.d);
+    inv_d = inverse3(d);
+    a = sqrlen(d);
+    medium = cx.medium_pos != REF_NONE;
+    neg_inv_density = xf.neg_inv_density;
+    object = cx.object;
+    kind = ref_kind(cx.body);
+    idx = ref_index(cx.body);
+    if (medium) cnt.template inc<ST_MEDIUM>();
+  }
+  // the primitive in its own frame: a box (p0, p1) or a sphere (c, radius)
+  const bool is_cube = kind == LEAF_CUBE;
+  Vec3<float> p0, p1;  // cube corners, or (centre, radius in p1.x)
+  if (is_cube) {
+    const Cube<float> c = sc.cubes[idx];
+    p0 = Vec3<float>(c.p0[0], c.p0[1], c.p0[2]);
+    p1 = Vec3<float>(c.p1[0], c.p1[1], c.p1[2]);
+  } else if (kind == LEAF_SPHERE) {
+    const Real4<float> sp = sc.spheres[idx];
+    p0 = Vec3<float>(sp.x, sp.y, sp.z);
+    p1 = Vec3<float>(sp.w, 0.0f, 0.0f);
+  } else {
+    const MSphere<float> m = sc.mspheres[idx];
+    p0 = moving_center(m, r.time);
+    p1 = Vec3<float>(m.radius, 0.0f, 0.0f);
+  }
+  // probe 0: the hit test proper, or a medium's first boundary probe; probe 1: a medium's second
+  float lo = medium ? -Consts<float>::inf : t_min, hi = medium ? Consts<float>::inf : t_max;
+  float t1 = 0.0f, t2 = 0.0f;
+  bool pending = true, ok = false;
+  for (int probe = 0; probe < 2; ++probe) {
+    if (pending) {
+      float t;
+      bool h;
+      if (medium) cnt.template inc<ST_MEDIUM_PROBES>();
+      if (is_cube) {  // hittable.rs:210-229
+        cnt.template inc<ST_CUBE_TESTS>();
+        const float blo[3] = {p0.x, p0.y, p0.z}, bhi[3] = {p1.x, p1.y, p1.z};
+        float l = lo, u = hi;
+        h = slab_hit(blo, bhi, o, inv_d, l, u);
+        t = l;
+        if (h) cnt.template inc<ST_CUBE_HITS>();
+      } else {  // hittable.rs:257-276 / 288-307
+        cnt.template inc<ST_SPHERE_TESTS>();
+        h = sphere_t(o, d, a, p0, p1.x, lo, hi, t);
+        if (h) cnt.template inc<ST_SPHERE_HITS>();
+      }
+      if (probe == 0) {
+        t1 = t;
+        ok = h;
+        pending = medium && h;
+        lo = second_probe_start(t1);  // hittable.rs:331
+      } else {
+        t2 = t;
+        ok = h;
+        pending = false;
+      }
+    }
+    if (!__any(pending)) break;
+  }
+  if (!ok) return false;
+  if (!medium) {
+    t_out = t1;
+    return true;
+  }
+  // hittable.rs:332-349
+  t1 = rmax(t1, t_min);
+  t2 = rmin(t2, t_max);
+  if (t1 >= t2) return false;
+  t1 = rmax(t1, 0.0f);
+  const float ray_length = length(r.d);  // rigid maps keep |d|
+  const float hit_distance = neg_inv_density * rlog(rng.template keyed<float>(object));
+  if (hit_distance > (t2 - t1) * ray_length) return false;
+  t_out = t1 + rdiv(hit_distance, ray_length);
+  return true;
+}
+
 // world.hit(r, t_min, +inf) — hittable.rs:400-412 as an iterative DFS.  `stack` is this
 // lane's column of the LDS stack: entry i lives at stack[i * stride].
 template <typename R, bool STATS>
@@ -263,7 +358,9 @@ RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng
     } else {
       R t;
       bool h;
-      if (ref_kind(cur) == LEAF_COMPLEX)
+      if constexpr (sizeof(R) == 4)
+        h = leaf_t_unified(sc, cur, r, inv_d, a, t_min, closest, rng, t, cnt);
+      else if (ref_kind(cur) == LEAF_COMPLEX)
         h = complex_t(sc, ref_index(cur), r, t_min, closest, rng, t, cnt);
       else
         h = prim_t(sc, cur, r, inv_d, a, t_min, closest, t, cnt);
@@ -350,11 +447,7 @@ struct OrderedWalk {
       }
     } else {
       float t;
-      bool h;
-      if (ref_kind(cur) == LEAF_COMPLEX)
-        h = complex_t(sc, ref_index(cur), r, t_min, t_incl, rng, t, cnt);
-      else
-        h = prim_t(sc, cur, r, inv_d, a, t_min, t_incl, t, cnt);
+      const bool h = leaf_t_unified(sc, cur, r, inv_d, a, t_min, t_incl, rng, t, cnt);
       if (h) {
         bool take = t < closest;
         if (t == closest && best != REF_NONE) take = leaf_rank(sc, cur) < leaf_rank(sc, best);
@@ -403,11 +496,7 @@ struct OrderedWalk {
                         const uint16_t* stack_t, uint32_t stride, Cnt<STATS>& cnt) {
     const float t_incl = next_up(closest);
     float t;
-    bool h;
-    if (ref_kind(cur) == LEAF_COMPLEX)
-      h = complex_t(sc, ref_index(cur), r, t_min, t_incl, rng, t, cnt);
-    else
-      h = prim_t(sc, cur, r, inv_d, a, t_min, t_incl, t, cnt);
+    const bool h = leaf_t_unified(sc, cur, r, inv_d, a, t_min, t_incl, rng, t, cnt);
     if (h) {
       bool take = t < closest;
       if (t == closest && best != REF_NONE) take = leaf_rank(sc, cur) < leaf_rank(sc, best);
