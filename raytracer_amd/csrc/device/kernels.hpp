@@ -673,6 +673,283 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
   if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&stats->v[ST_NONFINITE], (unsigned long long)nf);
 }
 
+// Small scenes, f32: the leaf-list megakernel with the workgroup's paths SORTED through LDS once per
+// vertex ("a wavefront queue that never leaves the CU").
+//
+// In render_kernel a lane owns a pixel, so every wave runs the camera code for the ~40 % of its
+// lanes whose path just ended and the scatter code for the ~57 % that hit a diffuse surface: VALU lane
+// utilisation 0.63.  Here a lane is a SLOT: after the closest hit and its record are known, the 256
+// slots of the workgroup are permuted through LDS so that the paths that need Material::scatter sit
+// in the low waves and the slots that need a new camera sample in the high waves; both code blocks
+// then run in (almost) full waves.  (pixel, sample) jobs are handed out from an LDS counter, the
+// radiance of a finished sample is added to the workgroup's LDS tile accumulator with ds_add_f32.
+// Same paths and draws as render_kernel (a job's Philox stream is keyed by pixel and sample, not by
+// lane); only the order in which a pixel's samples are summed differs.
+// MEASURED (Cornell 1024^2, profiles/r01_sorted_kernel_experiment.md): lane utilisation 0.63 -> 0.76 and
+// 8 % fewer VALU wave-instructions per ray, but three workgroup barriers per vertex and the state
+// traffic through LDS cost more than that buys: 22.0 ms against 18.6 ms per 256 spp.  Kept as an
+// opt-in experiment (RT_LINEAR_SORTED=1), not the default.
+constexpr uint32_t SORT_DWORDS = 20;
+#ifndef RT_SORTED_MIN_WAVES
+#define RT_SORTED_MIN_WAVES 5
+#endif
+template <bool STATS>
+__global__ void __launch_bounds__(BLOCK, RT_SORTED_MIN_WAVES) render_sorted_kernel(SceneView<float> sc, CameraView<float> cam,
+                                                                                 RenderArgs a, float* __restrict__ accum,
+                                                                                 DeviceStats* stats) {
+  using R = float;
+  __shared__ Light<R> s_lights[LDS_MAX_LIGHTS];
+  __shared__ float s_lin[LIN_MAX_LEAVES * LIN_DWORDS];
+  __shared__ uint32_t s_state[SORT_DWORDS * BLOCK];
+  __shared__ float s_acc[3 * BLOCK];
+  __shared__ uint32_t s_wave_flagged[BLOCK / 64];
+  __shared__ uint32_t s_job;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  {
+    const uint32_t n_l = sc.n_lights < LDS_MAX_LIGHTS ? sc.n_lights : LDS_MAX_LIGHTS;
+    constexpr uint32_t LW = sizeof(Light<R>) / 4;
+    for (uint32_t i = tid; i < n_l * LW; i += BLOCK)
+      reinterpret_cast<uint32_t*>(s_lights)[i] = reinterpret_cast<const uint32_t*>(sc.lights)[i];
+    for (uint32_t i = tid; i < sc.n_linear * LIN_DWORDS; i += BLOCK) s_lin[i] = __uint_as_float(sc.linear_rec[i]);
+    for (uint32_t i = tid; i < 3 * BLOCK; i += BLOCK) s_acc[i] = 0.0f;
+    if (tid == 0) s_job = 0;
+    __syncthreads();
+  }
+  const Light<R>* lights = sc.n_lights <= LDS_MAX_LIGHTS ? s_lights : sc.lights;
+  const uint32_t tiles_x = (a.width + 15u) / 16u;
+  const uint32_t tx0 = (blockIdx.x % tiles_x) * 16u, ty0 = (blockIdx.x / tiles_x) * 16u;
+  // local pixel lp of the 16x16 tile -> image coordinates (8x8 sub-tiles, like tile_pixel)
+  auto pixel_of = [&](uint32_t lp, uint32_t& px, uint32_t& py) {
+    px = tx0 + ((lp >> 6) & 1u) * 8u + (lp & 7u);
+    py = ty0 + (lp >> 7) * 8u + ((lp >> 3) & 7u);
+  };
+  const uint32_t s_begin = (uint32_t)(((uint64_t)a.n_samples * blockIdx.y) / a.splits);
+  const uint32_t s_end = (uint32_t)(((uint64_t)a.n_samples * (blockIdx.y + 1)) / a.splits);
+  const uint32_t total_jobs = BLOCK * (s_end - s_begin);  // job j: local pixel j % 256, sample s_begin + j / 256
+  const Vec3<R> background(sc.background[0], sc.background[1], sc.background[2]);
+
+  Cnt<STATS> cnt;
+  cnt.clear();
+  uint32_t nonfinite = 0;
+  bool alive = false;
+  Vec3<R> ro, rd, thr, L;
+  uint32_t lp = 0, smp = 0, depth_left = 0, slot = 0;
+  uint32_t boundary = 0;  // slots >= boundary may take a new job this iteration
+  Rng rng;
+  rng.init(a.seed, 0, 0);
+
+  // a finished sample: drop it if non-finite (DESIGN.md "f32 conditioning"), else add it to the tile
+  auto finish = [&]() {
+    const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
+    if (!fin) {
+      ++nonfinite;
+    } else {
+      atomicAdd(&s_acc[3 * lp + 0], L.x);
+      atomicAdd(&s_acc[3 * lp + 1], L.y);
+      atomicAdd(&s_acc[3 * lp + 2], L.z);
+    }
+    alive = false;
+  };
+
+  for (;;) {
+    // (A) free slots in the high waves take the next (pixel, sample) job: Camera::get_ray
+    if (!alive && tid >= boundary) {
+      const uint64_t m = __ballot(1);
+      const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&s_job, (uint32_t)__popcll(m));
+      base = __shfl(base, (int)leader, 64);
+      const uint32_t j = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (j < total_jobs) {
+        lp = j & (BLOCK - 1u);
+        smp = a.sample_begin + s_begin + (j >> 8);
+        uint32_t px, py;
+        pixel_of(lp, px, py);
+        if (px < a.width && py < a.height) {
+          rng.pixel = py * a.width + px;
+          rng.sample = smp;
+          rng.begin(0);
+          R ju = rng.next<R>();
+          R jv = rng.next<R>();
+          R u = rdiv((R)px + ju, (R)(a.width - 1));                  // main.rs:161
+          R v = rdiv((R)(a.height - py - 1) + jv, (R)(a.height - 1));  // main.rs:162-163
+          const RayT<R> cr = camera_ray(cam, u, v, rng);
+          ro = cr.o;
+          rd = cr.d;
+          thr = Vec3<R>(1, 1, 1);
+          L = Vec3<R>(0, 0, 0);
+          depth_left = a.max_depth;
+          slot = 1;
+          alive = true;
+        }
+      }
+    }
+    // all paths done and all jobs handed out?
+    if (!__syncthreads_or(alive ? 1 : 0) && s_job >= total_jobs) break;
+
+    // (B) closest hit: the leaf list (hittable.rs:387-399 over the BVH's leaves)
+    R t = R(0);
+    uint32_t best = REF_NONE;
+    if (alive) {
+      uint32_t px, py;
+      pixel_of(lp, px, py);
+      rng.pixel = py * a.width + px;
+      rng.sample = smp;
+      rng.set_slot(slot);
+      cnt.template inc<ST_RAYS>();
+      RayT<R> ray;
+      ray.o = ro;
+      ray.d = rd;
+      ray.time = R(0);  // leaf-list scenes hold no moving sphere
+      if (sc.linear_has_media)  // wave-uniform
+        traverse_linear<STATS, true>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+      else
+        traverse_linear<STATS, false>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+    }
+    // (C) the winner's HitRecord; misses and emitters end here (main.rs:101-104), the rest needs scatter
+    bool needs_scatter = false;
+    HitRec<R> h;
+    h.p = Vec3<R>(0, 0, 0);
+    h.normal = Vec3<R>(0, 0, 0);
+    h.uv.x = h.uv.y = R(0);
+    h.front_face = false;
+    if (alive) {
+      if (best == REF_NONE) {
+        cnt.template inc<ST_MISSES>();
+        L = L + thr * background;
+        finish();
+      } else {
+        cnt.template inc<ST_CLOSEST>();
+        RayT<R> ray;
+        ray.o = ro;
+        ray.d = rd;
+        ray.time = R(0);
+        Material<R> mat;
+        lin_hit_record(sc, s_lin + best * LIN_DWORDS, ray, t, h, mat);
+        if (mat.tag == MAT_DIFFUSE_LIGHT) {
+          cnt.template inc<ST_EMITTER>();
+          if (h.front_face) L = L + thr * material_color(sc, mat, h);
+          finish();
+        } else {
+          needs_scatter = true;
+        }
+      }
+    }
+    // (D) permute the workgroup's slots: scatter work to the low end, free slots to the high end
+    const uint64_t fm = __ballot(needs_scatter);
+    if (lane == 0) s_wave_flagged[wave] = (uint32_t)__popcll(fm);
+    __syncthreads();
+    uint32_t flagged_before = 0, flagged_total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < BLOCK / 64; ++w) {
+      const uint32_t c = s_wave_flagged[w];
+      flagged_before += w < wave ? c : 0u;
+      flagged_total += c;
+    }
+    const uint32_t in_wave = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+    const uint32_t pos = needs_scatter ? flagged_before + in_wave
+                                       : BLOCK - 1u - ((wave * 64u - flagged_before) + (lane - in_wave));
+    {
+      uint32_t* st = s_state + pos;
+      st[0 * BLOCK] = __float_as_uint(h.p.x);
+      st[1 * BLOCK] = __float_as_uint(h.p.y);
+      st[2 * BLOCK] = __float_as_uint(h.p.z);
+      st[3 * BLOCK] = __float_as_uint(rd.x);
+      st[4 * BLOCK] = __float_as_uint(rd.y);
+      st[5 * BLOCK] = __float_as_uint(rd.z);
+      st[6 * BLOCK] = __float_as_uint(h.normal.x);
+      st[7 * BLOCK] = __float_as_uint(h.normal.y);
+      st[8 * BLOCK] = __float_as_uint(h.normal.z);
+      st[9 * BLOCK] = __float_as_uint(thr.x);
+      st[10 * BLOCK] = __float_as_uint(thr.y);
+      st[11 * BLOCK] = __float_as_uint(thr.z);
+      st[12 * BLOCK] = __float_as_uint(L.x);
+      st[13 * BLOCK] = __float_as_uint(L.y);
+      st[14 * BLOCK] = __float_as_uint(L.z);
+      st[15 * BLOCK] = __float_as_uint(h.uv.x);
+      st[16 * BLOCK] = __float_as_uint(h.uv.y);
+      st[17 * BLOCK] = (best & 0xFFu) | (h.front_face ? 0x100u : 0u) | (lp << 16);
+      st[18 * BLOCK] = smp;
+      st[19 * BLOCK] = (depth_left & 0xFFFFu) | (slot << 16);
+    }
+    __syncthreads();
+    {
+      const uint32_t* st = s_state + tid;
+      h.p = Vec3<R>(__uint_as_float(st[0 * BLOCK]), __uint_as_float(st[1 * BLOCK]), __uint_as_float(st[2 * BLOCK]));
+      rd = Vec3<R>(__uint_as_float(st[3 * BLOCK]), __uint_as_float(st[4 * BLOCK]), __uint_as_float(st[5 * BLOCK]));
+      h.normal = Vec3<R>(__uint_as_float(st[6 * BLOCK]), __uint_as_float(st[7 * BLOCK]), __uint_as_float(st[8 * BLOCK]));
+      thr = Vec3<R>(__uint_as_float(st[9 * BLOCK]), __uint_as_float(st[10 * BLOCK]), __uint_as_float(st[11 * BLOCK]));
+      L = Vec3<R>(__uint_as_float(st[12 * BLOCK]), __uint_as_float(st[13 * BLOCK]), __uint_as_float(st[14 * BLOCK]));
+      h.uv.x = __uint_as_float(st[15 * BLOCK]);
+      h.uv.y = __uint_as_float(st[16 * BLOCK]);
+      const uint32_t m0 = st[17 * BLOCK], m2 = st[19 * BLOCK];
+      best = m0 & 0xFFu;
+      h.front_face = (m0 & 0x100u) != 0;
+      lp = m0 >> 16;
+      smp = st[18 * BLOCK];
+      depth_left = m2 & 0xFFFFu;
+      slot = m2 >> 16;
+    }
+    boundary = flagged_total;
+    alive = tid < boundary;
+    // (E) Material::scatter + the mixture pdf for the sorted paths (main.rs:77-100)
+    if (alive) {
+      uint32_t px, py;
+      pixel_of(lp, px, py);
+      rng.pixel = py * a.width + px;
+      rng.sample = smp;
+      rng.begin(slot);
+      const float* rec = s_lin + best * LIN_DWORDS;
+      Material<R> mat;
+      mat.tag = __float_as_uint(rec[LIN_MAT + 0]);
+      mat.texture = __float_as_uint(rec[LIN_MAT + 1]);
+      mat.flags = __float_as_uint(rec[LIN_MAT + 2]);
+      mat.pad = 0;
+      for (int i = 0; i < 4; ++i) mat.p[i] = rec[LIN_MAT + 4 + i];
+      for (int i = 0; i < 3; ++i) mat.color[i] = rec[LIN_MAT + 8 + i];
+      h.material = REF_NONE;
+      h.object = __float_as_uint(rec[LIN_OBJECT]);
+      RayT<R> ray;
+      ray.o = h.p;
+      ray.d = rd;
+      ray.time = R(0);
+      bool cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
+      ro = ray.o;
+      rd = ray.d;
+      ++slot;
+      --depth_left;
+      if (depth_left == 0) cont = false;  // the next ray_color call would return 0
+      if (cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
+      if (!cont) finish();
+    }
+  }
+  __syncthreads();
+  {
+    uint32_t px, py;
+    pixel_of(tid, px, py);
+    if (px < a.width && py < a.height) {
+      R* out = accum + 3ull * (py * a.width + px);
+      const R x = s_acc[3 * tid + 0], y = s_acc[3 * tid + 1], z = s_acc[3 * tid + 2];
+      if (a.splits > 1) {
+        atomicAdd(out + 0, x);
+        atomicAdd(out + 1, y);
+        atomicAdd(out + 2, z);
+      } else if (a.accumulate) {
+        out[0] += x;
+        out[1] += y;
+        out[2] += z;
+      } else {
+        out[0] = x;
+        out[1] = y;
+        out[2] = z;
+      }
+    }
+  }
+  flush_stats(cnt, stats);
+  uint32_t nf = wave_sum(nonfinite);
+  if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&stats->v[ST_NONFINITE], (unsigned long long)nf);
+}
+
 // world.hit() for the deterministic primary ray of every pixel: parity levels 1-2.
 template <typename R>
 __global__ void __launch_bounds__(BLOCK) primary_kernel(SceneView<R> sc, CameraView<R> cam, uint32_t width,

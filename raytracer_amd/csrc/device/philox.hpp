@@ -74,6 +74,12 @@ struct Rng {
     block = 0;
     refill();
   }
+  // select a slot without generating its first block (keyed draws only need the counter)
+  RT_DEV void set_slot(uint32_t slot_) {
+    slot = slot_;
+    block = 0;
+    have = 0;
+  }
   RT_DEV uint32_t next_u32() {
     if (have == 0) refill();
     uint32_t r = w0;

@@ -30,6 +30,15 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   a.pad = 0;
 #if RT_HAS_LINEAR
   if (shape.trav == TRAV_LINEAR) {
+    // opt-in experiment ("megakernel vs queue"): measured 18 % slower than render_kernel
+    static const bool sorted = getenv("RT_LINEAR_SORTED") != nullptr;
+    if (sorted && max_depth > 0 && max_depth < 65536) {
+      if (stats)
+        hipLaunchKernelGGL((render_sorted_kernel<true>), grid, block, 0, st, sc, cam, a, accum, dstats);
+      else
+        hipLaunchKernelGGL((render_sorted_kernel<false>), grid, block, 0, st, sc, cam, a, accum, dstats);
+      return hipGetLastError();
+    }
     if (stats)
       hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_LINEAR>), grid, block, 0, st, sc, cam, a,
                          accum, dstats);

@@ -198,3 +198,30 @@ def test_f32_tracks_f64_audit_at_equal_seed(name, earthmap):
         assert abs(ta / tb - 1.0) <= 0.01, (name, d, ta, tb)
         # (work counters are not compared: the f32 kernel stops a path at zero throughput, the audit kernel
         # walks it to the end like the reference)
+
+
+def test_sorted_kernel_experiment_renders_the_same_paths(earthmap):
+    """RT_LINEAR_SORTED=1 (read once per process, so a child process) selects the LDS-sorted variant of
+    the leaf-list kernel: same (pixel, sample) Philox streams, different summation order."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import raytracer_amd as R\n"
+        "hs = R.HostScene(6, 1.0); ds = R.DeviceScene(hs, 0)\n"
+        "a, st = ds.render(72, 72, 48, 50, seed=5, sample_offset=7, stats=True)\n"
+        "np.save(sys.argv[1], a); print(st['rays'])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = {}
+    for tag, env in (("default", {}), ("sorted", {"RT_LINEAR_SORTED": "1"})):
+        path = f"/tmp/rt_sorted_{tag}_{os.getpid()}.npy"
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code, path], env=e, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = (np.load(path), int(r.stdout.strip().splitlines()[-1]))
+        os.remove(path)
+    (a, ra), (b, rb) = out["default"], out["sorted"]
+    assert abs(ra - rb) <= 0.002 * ra  # a path may differ where a branch hangs on the last ulp
+    same = np.isclose(a, b, rtol=1e-4, atol=1e-5).all(axis=-1)
+    assert same.mean() >= 0.97, same.mean()
+    assert abs(a.sum() / b.sum() - 1.0) <= 0.005
