@@ -56,7 +56,11 @@ inline Counters*& tls_counters() {
   static thread_local Counters* cur = &dummy;
   return cur;
 }
+#ifdef ORC_NO_COUNT  // liboracle_nocount.so: the timed CPU baseline does not pay for the checker's counters
+#define ORC_COUNT(field) ((void)0)
+#else
 #define ORC_COUNT(field) (++tls_counters()->field)
+#endif
 
 // ---- aabb.rs ---------------------------------------------------------------------------
 struct AABB {

@@ -57,15 +57,17 @@ class OrcCounters(C.Structure):
         return {n: int(getattr(self, n)) for n in COUNTER_FIELDS}
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            raise RuntimeError(f"{_LIB_PATH} missing: run `make -C oracle` (or __graft_entry__.build())")
-        L = C.CDLL(_LIB_PATH)
+def lib(name="liboracle.so"):
+    """liboracle.so: the checker (counts its work, -O2, no fp contraction).  liboracle_nocount.so: the same
+    sources at -O3 without the work counters, for bench.py's timed CPU baseline only."""
+    if name not in _libs:
+        path = os.path.join(_ROOT, "oracle", name)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = C.CDLL(path)
         L.orc_last_error.restype = C.c_char_p
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.c_int, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
@@ -87,8 +89,8 @@ def lib():
         L.orc_bvh_axis.argtypes = [C.c_uint64, C.c_uint32]
         L.orc_scene_draws.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_path_draws.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
-        _lib = L
-    return _lib
+        _libs[name] = L
+    return _libs[name]
 
 
 def _ptr(a):
@@ -96,8 +98,9 @@ def _ptr(a):
 
 
 class OracleScene:
-    def __init__(self, scene_id, aspect_ratio, scene_seed=5, bvh_seed=7, n=0, rotate_bbox=-1, texels=None):
-        L = lib()
+    def __init__(self, scene_id, aspect_ratio, scene_seed=5, bvh_seed=7, n=0, rotate_bbox=-1, texels=None,
+                 library="liboracle.so"):
+        self._lib = L = lib(library)
         tw = th = 0
         tp = None
         if texels is not None:
@@ -112,7 +115,7 @@ class OracleScene:
 
     def close(self):
         if self._h:
-            lib().orc_scene_destroy(self._h)
+            self._lib.orc_scene_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -131,7 +134,7 @@ class OracleScene:
         boxes = np.zeros((max(n, 1), 6), dtype=np.float64)
         left = np.zeros(max(n, 1), dtype=np.uint32)
         right = np.zeros(max(n, 1), dtype=np.uint32)
-        root = lib().orc_bvh_preorder(self._h, _ptr(boxes), _ptr(left), _ptr(right))
+        root = self._lib.orc_bvh_preorder(self._h, _ptr(boxes), _ptr(left), _ptr(right))
         return root, boxes[:n], left[:n], right[:n]
 
     def primary_hits(self, w, h, seed=1, time=0.0):
@@ -140,7 +143,7 @@ class OracleScene:
         nrm = np.zeros((h, w, 3), dtype=np.float64)
         uv = np.zeros((h, w, 2), dtype=np.float64)
         ff = np.zeros((h, w), dtype=np.uint8)
-        lib().orc_primary_hits(self._h, w, h, seed, time, _ptr(ids), _ptr(t), _ptr(nrm), _ptr(uv), _ptr(ff))
+        self._lib.orc_primary_hits(self._h, w, h, seed, time, _ptr(ids), _ptr(t), _ptr(nrm), _ptr(uv), _ptr(ff))
         return ids, t, nrm, uv, ff
 
     def render(self, w, h, spp, max_depth, seed=1, sample_offset=0, threads=None):
@@ -148,7 +151,7 @@ class OracleScene:
             threads = os.cpu_count() or 1
         accum = np.zeros((h, w, 3), dtype=np.float64)
         cnt = OrcCounters()
-        secs = lib().orc_render(self._h, w, h, spp, max_depth, seed, sample_offset, threads, _ptr(accum),
+        secs = self._lib.orc_render(self._h, w, h, spp, max_depth, seed, sample_offset, threads, _ptr(accum),
                                 C.byref(cnt))
         return accum, cnt.as_dict(), secs
 
