@@ -1,0 +1,91 @@
+"""Edge cases of the render entry points on the GPU, for every kernel family: the leaf-list kernel
+(cornell_box), the ordered-walk refill kernel (random_scene), the reference-order f32 walk
+(simple_light) and the f64 audit kernel.  The reference's own edge behaviour is cited per test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FAMILIES = [("cornell_box", 6, 1.0, {}), ("random_scene", 0, 16.0 / 9.0, {}), ("simple_light", 3, 1.5, {}),
+            ("small_scene_f64", 5, 1.5, {"f64": True})]
+
+
+def _scene(sid, asp):
+    import raytracer_amd as R
+    hs = R.HostScene(sid, asp)
+    return R, hs, R.DeviceScene(hs, 0)
+
+
+@pytest.mark.parametrize("name,sid,asp,kw", FAMILIES)
+def test_sample_ranges_compose(name, sid, asp, kw):
+    """Samples are keyed by their GLOBAL index (main.rs:160-166 made reproducible): rendering [0,5) and
+    [5,16) separately, in one call, or in launches of 3 gives the same sums up to f32 summation order —
+    what sample sharding across GPUs relies on."""
+    R, hs, ds = _scene(sid, asp)
+    w, h = 50, 37  # not multiples of the 16x16 tile
+    whole, sw = ds.render(w, h, 16, 8, seed=4, sample_offset=100, stats=True, **kw)
+    a, sa = ds.render(w, h, 5, 8, seed=4, sample_offset=100, stats=True, **kw)
+    b, sb = ds.render(w, h, 11, 8, seed=4, sample_offset=105, stats=True, **kw)
+    c, sc = ds.render(w, h, 16, 8, seed=4, sample_offset=100, spp_per_launch=3, stats=True, **kw)
+    assert sa["rays"] + sb["rays"] == sw["rays"] == sc["rays"]
+    assert sc["launches"] == 6
+    tol = dict(rtol=1e-12, atol=1e-12) if kw.get("f64") else dict(rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(a + b, whole, **tol)
+    np.testing.assert_allclose(c, whole, **tol)
+
+
+@pytest.mark.parametrize("name,sid,asp,kw", FAMILIES)
+def test_depth_zero_one_and_no_samples(name, sid, asp, kw):
+    R, hs, ds = _scene(sid, asp)
+    w, h = 33, 18
+    # main.rs:73-75: depth 0 -> black whatever the scene
+    z, sz = ds.render(w, h, 4, 0, seed=1, stats=True, **kw)
+    assert not z.any() and sz["rays"] == 0
+    # depth 1: one ray per sample; only emitted light and the background can arrive
+    o, so = ds.render(w, h, 4, 1, seed=1, stats=True, **kw)
+    assert so["rays"] == w * h * 4
+    assert so["closest_hits"] + so["misses"] == so["rays"]
+    # no samples: the accumulator is cleared
+    n, sn = ds.render(w, h, 0, 5, seed=1, stats=True, **kw)
+    assert not n.any() and sn["rays"] == 0
+
+
+def test_render_device_accumulates_and_tonemaps_like_the_host():
+    import torch
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    hs = R.HostScene(6, 1.0)
+    ds = R.DeviceScene(hs, 0)
+    w = h = 40
+    acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    ds.render_device(acc.data_ptr(), w, h, 8, 6, seed=3, sample_offset=0)
+    ds.render_device(acc.data_ptr(), w, h, 8, 6, seed=3, sample_offset=8, accumulate=True)
+    torch.cuda.synchronize()
+    both, _ = ds.render(w, h, 16, 6, seed=3)
+    np.testing.assert_allclose(acc.cpu().numpy(), both, rtol=2e-5, atol=1e-5)
+    rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    F.check_hip(F.hip.rt_tonemap_device(0, acc.data_ptr(), w * h, 16, rgb.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(rgb.cpu().numpy(), R.tonemap(acc.cpu().numpy(), 16))
+
+
+def test_arguments_are_validated_not_trusted():
+    """The reference panics (cam.rs:69 empty shutter range) or divides by zero (main.rs:161-163, w-1);
+    the library returns an error code and a message instead."""
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    hs = R.HostScene(6, 1.0)
+    ds = R.DeviceScene(hs, 0)
+    with pytest.raises(RuntimeError, match="2x2"):
+        ds.render(1, 8, 1, 1)
+    cam = F.RtCamera()
+    C.memmove(C.byref(cam), C.byref(hs.camera), C.sizeof(cam))
+    cam.time_close = cam.time_open
+    with pytest.raises(RuntimeError, match="shutter"):
+        ds.render(8, 8, 1, 1, camera=cam)
+    with pytest.raises(RuntimeError, match="32 bits"):
+        ds.render(8, 8, 16, 1, sample_offset=0xFFFFFFF8)
+    tiny, st = ds.render(2, 2, 3, 4, stats=True)  # the smallest legal image
+    assert tiny.shape == (2, 2, 3) and st["rays"] >= 12
