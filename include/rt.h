@@ -170,7 +170,7 @@ typedef struct rt_params {
   uint32_t max_depth;       /* main.rs:47-48 */
   uint64_t seed;            /* Philox key */
   uint64_t sample_offset;   /* global index of this call's first sample (multi-GPU sharding) */
-  uint32_t spp_per_launch;  /* 0 = library default */
+  uint32_t spp_per_launch;  /* samples per kernel launch; 0 = library default (4096) */
   uint32_t flags;           /* RT_FLAG_* */
 } rt_params;
 

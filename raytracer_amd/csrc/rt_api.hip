@@ -742,7 +742,9 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   const uint32_t n_nodes = s->n_nodes;
   sh.refill_eighths = re ? (uint32_t)std::min(8, std::max(1, atoi(re))) : n_nodes <= 4096 ? 5u : n_nodes <= 65536 ? 4u : 3u;
   uint32_t waves = sh.tiles * 4;
-  uint32_t splits = waves >= TARGET_WAVES ? 1 : (TARGET_WAVES + waves - 1) / waves;
+  static const char* tw = getenv("RT_TARGET_WAVES");  // tuning override
+  const uint32_t target = tw ? (uint32_t)std::max(1, atoi(tw)) : TARGET_WAVES;
+  uint32_t splits = waves >= target ? 1 : (target + waves - 1) / waves;
   sh.splits = std::max(1u, std::min(splits, n_samples));
   return sh;
 }
@@ -809,7 +811,10 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
   const bool want_stats = (p->flags & RT_FLAG_STATS) != 0;
   CameraView<R> cv = to_camera<R>(*cam);
   const SceneView<R>& sv = Side<R>::get(s).view;
-  uint32_t per_launch = p->spp_per_launch ? p->spp_per_launch : 64u;
+  // One launch renders up to 4096 samples of every pixel: a lane keeps regenerating samples in its loop, so
+  // long launches amortise the wave start-up and the tail in which the lanes of a wave run out of
+  // samples one by one (measured on Cornell 1024^2 x 4096 spp: 64 per launch 40.3, 256: 43.1, 4096: 45.2 Grays/s).
+  uint32_t per_launch = p->spp_per_launch ? p->spp_per_launch : 4096u;
   HIP_TRY(hipMemsetAsync(s->dstats, 0, sizeof(DeviceStats), stream));
   HIP_TRY(hipEventRecord(s->ev0, stream));
   uint32_t done = 0, launches = 0;
