@@ -349,6 +349,8 @@ struct RenderArgs {
   uint32_t splits;      // gridDim.y: each block row renders a slice of the launch's samples
   uint32_t stack_depth; // LDS traversal-stack entries per lane
   uint32_t refill_eighths;  // render_refill_kernel: refill when this many eighths of the unfinished lanes idle (1..8)
+  uint32_t unit_samples;    // render_persist_kernel: samples per (8x8 tile, sample range) unit
+  uint32_t wave_tiles_x, wave_tiles, total_units;
   uint32_t pad;
   uint64_t seed;
 };
@@ -666,6 +668,166 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
       out[0] = acc.x;
       out[1] = acc.y;
       out[2] = acc.z;
+    }
+  }
+  flush_stats(cnt, stats);
+  uint32_t nf = wave_sum(nonfinite);
+  if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&stats->v[ST_NONFINITE], (unsigned long long)nf);
+}
+
+// Small scenes, f32, PERSISTENT form of the leaf-list megakernel (the default for TRAV_LINEAR).
+//
+// render_kernel gives a wave one 8x8 tile and every lane a fixed quota of its pixel's samples: the wave
+// lasts as long as its unluckiest lane (path lengths vary: ~6 % idle at a 683-sample quota), and the
+// launch as long as its last round of waves.  Here the work is cut into UNITS (one 8x8 tile x
+// unit_samples samples) handed out from a global counter; a wave keeps a ring of the units it has
+// drawn in LDS and every lane walks that list AT ITS OWN PACE — a lane that finishes its pixel's
+// samples of unit i goes straight on to unit i+1 while its neighbours are still in unit i.  Nobody
+// waits for anybody until the global counter runs dry, when the stragglers are at most one unit apart.
+// A finished (pixel, unit) sum is added to the accumulator with a float atomic (units of one pixel run
+// on different waves).  Same paths and draws as render_kernel: a sample's Philox stream is keyed by
+// (pixel, sample), not by who renders it.
+constexpr uint32_t UNIT_RING = 32;
+template <bool STATS>
+__global__ void __launch_bounds__(BLOCK, RT_LINEAR_MIN_WAVES) render_persist_kernel(SceneView<float> sc, CameraView<float> cam,
+                                                                                  RenderArgs a, float* __restrict__ accum,
+                                                                                  DeviceStats* stats) {
+  using R = float;
+  __shared__ Light<R> s_lights[LDS_MAX_LIGHTS];
+  __shared__ float s_lin[LIN_MAX_LEAVES * LIN_DWORDS];
+  __shared__ volatile uint32_t s_unit_xy[BLOCK / 64][UNIT_RING];  // tile origin x | y << 16
+  __shared__ volatile uint32_t s_unit_k[BLOCK / 64][UNIT_RING];   // which sample range of the launch
+  __shared__ uint32_t s_red[BLOCK / 64][2];                       // wave-wide max / min scratch
+  {
+    const uint32_t n_l = sc.n_lights < LDS_MAX_LIGHTS ? sc.n_lights : LDS_MAX_LIGHTS;
+    constexpr uint32_t LW = sizeof(Light<R>) / 4;
+    for (uint32_t i = threadIdx.x; i < n_l * LW; i += BLOCK)
+      reinterpret_cast<uint32_t*>(s_lights)[i] = reinterpret_cast<const uint32_t*>(sc.lights)[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_linear * LIN_DWORDS; i += BLOCK) s_lin[i] = __uint_as_float(sc.linear_rec[i]);
+    __syncthreads();
+  }
+  const Light<R>* lights = sc.n_lights <= LDS_MAX_LIGHTS ? s_lights : sc.lights;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const Vec3<R> background(sc.background[0], sc.background[1], sc.background[2]);
+
+  Cnt<STATS> cnt;
+  cnt.clear();
+  uint32_t nonfinite = 0;
+  Vec3<R> acc;
+  uint32_t list_len = 0;    // wave-uniform: units this wave has drawn so far
+  bool exhausted = false;   // wave-uniform: the global counter has run dry
+  uint32_t ui = 0xFFFFFFFFu;  // this lane's position in the wave's list (none yet)
+  uint32_t s = 0, s_end = 0, px = 0, py = 0;
+  bool have_pixel = false, lane_done = false, alive = false;
+  RayT<R> ray;
+  Vec3<R> thr, L;
+  uint32_t depth_left = 0, slot = 0;
+  Rng rng;
+  rng.init(a.seed, 0, 0);
+
+  for (;;) {
+    // (0) lanes that have finished their pixel's samples of a unit move on to the wave's next unit
+    const bool needy = !alive && s == s_end && !lane_done;
+    if (__ballot(needy)) {  // wave-uniform
+      if (needy && have_pixel) {
+        float* out = accum + 3ull * (py * a.width + px);
+        atomicAdd(out + 0, acc.x);
+        atomicAdd(out + 1, acc.y);
+        atomicAdd(out + 2, acc.z);
+        acc = Vec3<R>(0, 0, 0);
+        have_pixel = false;
+      }
+      const uint32_t leader = (uint32_t)__builtin_ctzll(__ballot(1));
+      if (lane == leader) {
+        s_red[wave][0] = 0u;
+        s_red[wave][1] = 0xFFFFFFFFu;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (needy) atomicMax(&s_red[wave][0], ui + 2u);  // the list must reach index ui + 1
+      if (!lane_done) atomicMin(&s_red[wave][1], ui + 1u);  // the oldest entry anybody may still read
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t want = ((volatile uint32_t*)s_red[wave])[0];
+      const uint32_t oldest = ((volatile uint32_t*)s_red[wave])[1];
+      while (list_len < want && !exhausted && list_len - oldest < UNIT_RING) {  // wave-uniform
+        uint32_t u = 0;
+        if (lane == leader) u = atomicAdd(&stats->unit_counter, 1u);
+        u = __shfl(u, (int)leader, 64);
+        if (u >= a.total_units) {
+          exhausted = true;
+          break;
+        }
+        if (lane == leader) {
+          const uint32_t tile = u % a.wave_tiles;
+          s_unit_xy[wave][list_len % UNIT_RING] = ((tile % a.wave_tiles_x) * 8u) | (((tile / a.wave_tiles_x) * 8u) << 16);
+          s_unit_k[wave][list_len % UNIT_RING] = u / a.wave_tiles;
+        }
+        ++list_len;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (needy) {
+        if (ui + 1u < list_len) {
+          ++ui;
+          const uint32_t xy = s_unit_xy[wave][ui % UNIT_RING], k = s_unit_k[wave][ui % UNIT_RING];
+          px = (xy & 0xFFFFu) + (lane & 7u);
+          py = (xy >> 16) + (lane >> 3);
+          s = k * a.unit_samples;
+          s_end = s + a.unit_samples < a.n_samples ? s + a.unit_samples : a.n_samples;
+          have_pixel = px < a.width && py < a.height;
+          if (!have_pixel) s = s_end;  // a tile that straddles the image edge: nothing to do for this lane
+          rng.pixel = py * a.width + px;
+        } else if (exhausted) {
+          lane_done = true;
+        }  // else: the ring is full; try again once the slowest lane has moved on
+      }
+    }
+    if (!alive) {
+      if (s == s_end) {
+        if (lane_done) break;
+        continue;
+      }
+      rng.sample = a.sample_begin + s;
+      ++s;
+      rng.begin(0);
+      R ju = rng.next<R>();
+      R jv = rng.next<R>();
+      R u = rdiv((R)px + ju, (R)(a.width - 1));                  // main.rs:161
+      R v = rdiv((R)(a.height - py - 1) + jv, (R)(a.height - 1));  // main.rs:162-163
+      ray = camera_ray(cam, u, v, rng);
+      thr = Vec3<R>(1, 1, 1);
+      L = Vec3<R>(0, 0, 0);
+      depth_left = a.max_depth;
+      slot = 1;
+      alive = true;
+    }
+    rng.begin(slot);
+    cnt.template inc<ST_RAYS>();
+    R t;
+    uint32_t best;
+    if (sc.linear_has_media)  // wave-uniform
+      traverse_linear<STATS, true>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+    else
+      traverse_linear<STATS, false>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+    bool cont;
+    if (best == REF_NONE) {  // main.rs:104
+      cnt.template inc<ST_MISSES>();
+      L = L + thr * background;
+      cont = false;
+    } else {
+      cnt.template inc<ST_CLOSEST>();
+      HitRec<R> h;
+      Material<R> mat;
+      lin_hit_record(sc, s_lin + best * LIN_DWORDS, ray, t, h, mat);
+      cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
+    }
+    ++slot;
+    --depth_left;
+    if (depth_left == 0) cont = false;  // the next ray_color call would return 0
+    if (cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
+    if (!cont) {
+      const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
+      if (!fin) ++nonfinite;
+      if (fin) acc = acc + L;
+      alive = false;
     }
   }
   flush_stats(cnt, stats);

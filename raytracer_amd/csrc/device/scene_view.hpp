@@ -137,6 +137,8 @@ template <typename R> struct CameraView {  // cam.rs:6-18
 struct DeviceStats {  // one uint64 per rt_stats counter, in rt_stats order
   unsigned long long v[17];
   unsigned long long stamp[8];  // RT_STAMPS diagnostic builds only: wave-cycles per loop phase
+  unsigned int unit_counter;    // render_persist_kernel: next (tile, sample range) unit; zeroed per launch
+  unsigned int pad;
 };
 enum StatIdx {
   ST_RAYS = 0, ST_LIGHT_PROBES, ST_MEDIUM_PROBES, ST_NODES, ST_SPHERE_TESTS, ST_SPHERE_HITS,

@@ -27,8 +27,19 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   size_t lds = (size_t)shape.stack_depth * BLOCK * sizeof(uint32_t);
   a.stack_depth = shape.stack_depth;
   a.refill_eighths = shape.refill_eighths;
+  a.unit_samples = shape.unit_samples;
+  a.wave_tiles_x = shape.wave_tiles_x;
+  a.wave_tiles = shape.wave_tiles;
+  a.total_units = shape.total_units;
   a.pad = 0;
 #if RT_HAS_LINEAR
+  if (shape.trav == TRAV_LINEAR && shape.unit_samples > 0) {  // persistent form: grid = workers, not tiles
+    if (stats)
+      hipLaunchKernelGGL((render_persist_kernel<true>), grid, block, 0, st, sc, cam, a, accum, dstats);
+    else
+      hipLaunchKernelGGL((render_persist_kernel<false>), grid, block, 0, st, sc, cam, a, accum, dstats);
+    return hipGetLastError();
+  }
   if (shape.trav == TRAV_LINEAR) {
     // opt-in experiment ("megakernel vs queue"): measured 18 % slower than render_kernel
     static const bool sorted = getenv("RT_LINEAR_SORTED") != nullptr;

@@ -731,7 +731,7 @@ int check_camera(const rt_camera* cam) {
 }
 
 LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_samples, bool f32_fast = false,
-                       const rt_camera* cam = nullptr) {
+                       const rt_camera* cam = nullptr, uint32_t max_depth = 0) {
   LaunchShape sh;
   sh.trav = 0;  // the reference's left-first walk: always valid
   if (f32_fast && s->boxes_conservative && cam && cam->time_open >= s->safe_t_lo && cam->time_close <= s->safe_t_hi)
@@ -749,6 +749,26 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   const uint32_t target = tw ? (uint32_t)std::max(1, atoi(tw)) : TARGET_WAVES;
   uint32_t splits = waves >= target ? 1 : (target + waves - 1) / waves;
   sh.splits = std::max(1u, std::min(splits, n_samples));
+  // Leaf-list scenes: persistent workers drawing (8x8 tile, sample range) units from a global counter
+  // (render_persist_kernel).  Off for max_depth 0 (handled by render_kernel) and with RT_LINEAR_NO_PERSIST (A/B).
+  static const bool no_persist = getenv("RT_LINEAR_NO_PERSIST") != nullptr || getenv("RT_LINEAR_SORTED") != nullptr;
+  static const char* us = getenv("RT_UNIT_SAMPLES");
+  if (sh.trav == 1 && !no_persist && max_depth > 0) {
+    // unit size: large enough to amortise the hand-over (measured optimum 256 at 4096 spp, 64 at 256 spp),
+    // small enough that the launch has many units per worker
+    const uint32_t auto_unit = std::min(256u, std::max(16u, n_samples / 4));
+    sh.unit_samples = std::max(1u, std::min(us ? (uint32_t)std::max(1, atoi(us)) : auto_unit, n_samples));
+    sh.wave_tiles_x = (w + 7) / 8;
+    sh.wave_tiles = sh.wave_tiles_x * ((h + 7) / 8);
+    const uint64_t units = (uint64_t)sh.wave_tiles * ((n_samples + sh.unit_samples - 1) / sh.unit_samples);
+    if (units <= 0xFFFFFFFFull && n_samples > 0) {
+      sh.total_units = (uint32_t)units;
+      sh.tiles = (uint32_t)std::min<uint64_t>((units + 3) / 4, 256u * 8u);  // workgroups: at most 8 per CU can be resident
+      sh.splits = 1;
+    } else {
+      sh.unit_samples = 0;
+    }
+  }
   return sh;
 }
 
@@ -826,9 +846,10 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
   if (p->spp == 0 && !accumulate) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
   while (done < p->spp) {
     uint32_t n = std::min(per_launch, p->spp - done);
-    LaunchShape sh = make_shape(s, p->width, p->height, n, sizeof(R) == 4 && !(p->flags & RT_FLAG_FORCE_BVH), cam);
+    LaunchShape sh = make_shape(s, p->width, p->height, n, sizeof(R) == 4 && !(p->flags & RT_FLAG_FORCE_BVH), cam, p->max_depth);
     int acc = (accumulate || !first) ? 1 : 0;
-    if (sh.splits > 1 && !acc) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
+    if ((sh.splits > 1 || sh.unit_samples > 0) && !acc) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
+    if (sh.unit_samples > 0) HIP_TRY(hipMemsetAsync(&s->dstats->unit_counter, 0, sizeof(unsigned int), stream));
     HIP_TRY(Side<R>::render(sv, cv, p->width, p->height, (uint32_t)(p->sample_offset + done), n, p->max_depth, p->seed,
                             acc, want_stats, d_accum, s->dstats, sh, stream));
     done += n;
