@@ -193,7 +193,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                "frac": hbm_frac, "traffic": None}
         out["roofline"].update({
-            "kernel": "render_refill_kernel" if "ordered" in counted_on else "render_kernel<float>",
+            "kernel": "render_refill_kernel" if "ordered" in counted_on else "render_persist_kernel",
             "algorithmic_work_counted_on": counted_on, "avg_launch_ms": avg_launch_ms, "launches": launches,
             "algorithmic_flops_per_ray": flops_per_ray, "algorithmic_bytes_per_ray": bytes_per_ray,
             "algorithmic_tflops": tflops, "algorithmic_gbps": gbps,
