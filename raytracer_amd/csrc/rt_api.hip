@@ -761,7 +761,7 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
     sh.wave_tiles_x = (w + 7) / 8;
     sh.wave_tiles = sh.wave_tiles_x * ((h + 7) / 8);
     const uint64_t units = (uint64_t)sh.wave_tiles * ((n_samples + sh.unit_samples - 1) / sh.unit_samples);
-    if (units <= 0xFFFFFFFFull && n_samples > 0) {
+    if (units <= 0xFFF00000ull && n_samples > 0) {  // (every wave overshoots the counter once: keep clear of 2^32)
       sh.total_units = (uint32_t)units;
       sh.tiles = (uint32_t)std::min<uint64_t>((units + 3) / 4, 256u * 8u);  // workgroups: at most 8 per CU can be resident
       sh.splits = 1;
