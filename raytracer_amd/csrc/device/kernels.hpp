@@ -688,8 +688,11 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
 // on different waves).  Same paths and draws as render_kernel: a sample's Philox stream is keyed by
 // (pixel, sample), not by who renders it.
 constexpr uint32_t UNIT_RING = 32;
+#ifndef RT_PERSIST_MIN_WAVES
+#define RT_PERSIST_MIN_WAVES 5  // measured: 5 (no spills) 54.9, 6 (a few spills) 54.3, 7: 41.2 Grays/s
+#endif
 template <bool STATS>
-__global__ void __launch_bounds__(BLOCK, RT_LINEAR_MIN_WAVES) render_persist_kernel(SceneView<float> sc, CameraView<float> cam,
+__global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_kernel(SceneView<float> sc, CameraView<float> cam,
                                                                                   RenderArgs a, float* __restrict__ accum,
                                                                                   DeviceStats* stats) {
   using R = float;
