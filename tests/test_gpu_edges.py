@@ -89,3 +89,40 @@ def test_arguments_are_validated_not_trusted():
         ds.render(8, 8, 16, 1, sample_offset=0xFFFFFFF8)
     tiny, st = ds.render(2, 2, 3, 4, stats=True)  # the smallest legal image
     assert tiny.shape == (2, 2, 3) and st["rays"] >= 12
+
+
+def test_non_sphere_light_follows_hittable_rs_498_513():
+    """Q8: a light that is not a Sphere has pdf_value 0 and random() = (1, 0, 0).  None of the nine scenes
+    has one, so simple_light's second light is re-tagged RT_LIGHT_OTHER in a copy of the description; the
+    f32 and f64 kernels implement the arm independently (shared code aside) and must agree with each other at
+    equal seed, and the image must change (the arm is live)."""
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    hs = R.HostScene(3, 1.5)
+    d = F.RtSceneDesc()
+    C.memmove(C.byref(d), C.byref(hs.desc), C.sizeof(d))
+    tags = (C.c_uint8 * 2)(hs.desc.light_tag[0], 1)  # RT_LIGHT_SPHERE, RT_LIGHT_OTHER
+    d.light_tag = C.cast(tags, type(d.light_tag))
+
+    class Mutated(R.DeviceScene):
+        def __init__(self):
+            self.host = hs
+            self.device = 0
+            h = C.c_void_p()
+            F.check_hip(F.hip.rt_scene_create(0, C.byref(d), C.byref(h)))
+            self._h = h
+
+    ds, ref = Mutated(), R.DeviceScene(hs, 0)
+    w, h = 48, 32
+    a, _ = ds.render(w, h, 64, 3, seed=2)
+    b, _ = ds.render(w, h, 64, 3, seed=2, f64=True)
+    c, _ = ref.render(w, h, 64, 3, seed=2)
+    # (1,0,0) below the horizon with pdf 0 gives 0/0 (Q10): the f64 kernel lets it poison the pixel like the
+    # reference, the f32 kernel drops the sample -- compare the pixels no such sample fell into
+    ok = np.isfinite(b).all(axis=-1)
+    assert 0.2 < ok.mean() < 1.0
+    ta, tb = float(a[ok].sum()), float(b[ok].sum())
+    assert abs(ta / tb - 1.0) <= 0.01, (ta, tb)
+    same = np.isclose(a[ok], b[ok], rtol=1e-3, atol=1e-4).all(axis=-1)
+    assert same.mean() >= 0.75  # (64 samples per pixel: one f32-vs-f64 branch flip anywhere makes a pixel differ)
+    assert not np.allclose(c, a, rtol=1e-3, atol=1e-3)  # the arm is live: the estimate changed
