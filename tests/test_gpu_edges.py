@@ -126,3 +126,70 @@ def test_non_sphere_light_follows_hittable_rs_498_513():
     same = np.isclose(a[ok], b[ok], rtol=1e-3, atol=1e-4).all(axis=-1)
     assert same.mean() >= 0.75  # (64 samples per pixel: one f32-vs-f64 branch flip anywhere makes a pixel differ)
     assert not np.allclose(c, a, rtol=1e-3, atol=1e-3)  # the arm is live: the estimate changed
+
+
+def _arr(ptr, n, dtype):
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype).copy() if n else np.zeros(0, dtype)
+
+
+def test_cornell_smoke_exercises_the_leaf_list_medium_arm():
+    """No reference scene puts a constant medium into a small scene, so the leaf-list kernels' medium arm
+    (traverse_linear<MEDIA = true>, cube boundaries, hittable.rs:319-363) would go untested: turn the Cornell
+    box's two blocks into smoke (Shirley's cornell_smoke: ConstantMedium(Translate(Rotate(Cube))), density 0.01,
+    black and white Isotropic) in a copy of the description.  Leaf-list f32, reference-order f32 and the f64
+    audit kernel must agree at equal seed."""
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    hs = R.HostScene(6, 1.0)
+    src = hs.desc
+    assert src.n_complex == 2 and src.n_ops == 4
+    d = F.RtSceneDesc()
+    C.memmove(C.byref(d), C.byref(src), C.sizeof(d))
+    keep = []  # numpy arrays the description points into
+
+    def put(field, a, ptype):
+        a = np.ascontiguousarray(a)
+        keep.append(a)
+        setattr(d, field, a.ctypes.data_as(ptype))
+
+    op_tag = _arr(src.op_tag, 4, np.uint8)
+    op_data = _arr(src.op_data, 16, np.float64).reshape(4, 4)
+    med = lambda density: np.array([[-1.0 / density, 0, 0, 0]])
+    put("op_tag", np.concatenate([[2], op_tag[0:2], [2], op_tag[2:4]]).astype(np.uint8), F._u8p)
+    put("op_data", np.concatenate([med(0.01), op_data[0:2], med(0.01), op_data[2:4]]).astype(np.float64), F._f64p)
+    d.n_ops = 6
+    put("complex_op_first", np.array([0, 3], dtype=np.uint32), F._u32p)
+    put("complex_op_count", np.array([3, 3], dtype=np.uint32), F._u32p)
+    nm, nt = src.n_materials, src.n_textures
+    put("mat_tag", np.concatenate([_arr(src.mat_tag, nm, np.uint8), [4, 4]]).astype(np.uint8), F._u8p)  # RT_MAT_ISOTROPIC
+    put("mat_texture", np.concatenate([_arr(src.mat_texture, nm, np.uint32), [nt, nt + 1]]).astype(np.uint32), F._u32p)
+    put("mat_params", np.concatenate([_arr(src.mat_params, 4 * nm, np.float64), np.zeros(8)]), F._f64p)
+    d.n_materials = nm + 2
+    put("complex_material", np.array([nm, nm + 1], dtype=np.uint32), F._u32p)
+    put("tex_tag", np.concatenate([_arr(src.tex_tag, nt, np.uint8), [0, 0]]).astype(np.uint8), F._u8p)
+    put("tex_color", np.concatenate([_arr(src.tex_color, 3 * nt, np.float64), [0, 0, 0, 1, 1, 1]]), F._f64p)
+    for f, ty, pt in (("tex_odd", np.uint32, F._u32p), ("tex_even", np.uint32, F._u32p),
+                      ("tex_texel_offset", np.uint64, F._u64p), ("tex_width", np.uint32, F._u32p),
+                      ("tex_height", np.uint32, F._u32p)):
+        put(f, np.concatenate([_arr(getattr(src, f), nt, ty), [0, 0]]).astype(ty), pt)
+    d.n_textures = nt + 2
+
+    class Smoke(R.DeviceScene):
+        def __init__(self):
+            self.host = hs
+            self.device = 0
+            h = C.c_void_p()
+            F.check_hip(F.hip.rt_scene_create(0, C.byref(d), C.byref(h)))
+            self._h = h
+
+    ds = Smoke()
+    w = h = 64
+    a, sa = ds.render(w, h, 64, 4, seed=8, stats=True)                    # leaf list + medium arm
+    b, sb = ds.render(w, h, 64, 4, seed=8, stats=True, force_bvh=True)    # reference-order walk, f32
+    c, sc = ds.render(w, h, 64, 4, seed=8, stats=True, f64=True)          # audit
+    assert sa["nodes_visited"] == 0 and sb["nodes_visited"] > 0
+    assert sa["medium_visits"] > 0 and sa["medium_probes"] > sa["medium_visits"]
+    for x, y in ((a, b), (a, c)):
+        assert abs(float(x.sum()) / float(y[np.isfinite(y)].sum()) - 1.0) <= 0.01
+    plain, _ = R.DeviceScene(hs, 0).render(w, h, 64, 4, seed=8)
+    assert not np.allclose(plain, a, rtol=1e-2, atol=1e-2)  # smoke is not a solid block
