@@ -193,3 +193,23 @@ def test_cornell_smoke_exercises_the_leaf_list_medium_arm():
         assert abs(float(x.sum()) / float(y[np.isfinite(y)].sum()) - 1.0) <= 0.01
     plain, _ = R.DeviceScene(hs, 0).render(w, h, 64, 4, seed=8)
     assert not np.allclose(plain, a, rtol=1e-2, atol=1e-2)  # smoke is not a solid block
+
+
+def test_shutter_outside_the_moving_spheres_box_window_falls_back():
+    """new_bvh boxes the moving spheres over t in [0, 1] (main.rs:125); the ordered walk culls by those boxes,
+    so a camera whose shutter leaves that window must take the reference-order walk (which reproduces
+    whatever the reference's pruning does there)."""
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    hs = R.HostScene(0, 16.0 / 9.0)
+    ds = R.DeviceScene(hs, 0)
+    cam = F.RtCamera()
+    C.memmove(C.byref(cam), C.byref(hs.camera), C.sizeof(cam))
+    cam.time_open, cam.time_close = 0.5, 1.5
+    w, h = 64, 36
+    a, sa = ds.render(w, h, 8, 10, seed=3, stats=True, camera=cam)
+    b, sb = ds.render(w, h, 8, 10, seed=3, stats=True, camera=cam, force_bvh=True)
+    assert sa["nodes_visited"] == sb["nodes_visited"]
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)  # same kernel; float atomics of the sample splits reorder
+    inside, si = ds.render(w, h, 8, 10, seed=3, stats=True)  # shutter 0..1: the ordered walk
+    assert si["nodes_visited"] < sb["nodes_visited"]
