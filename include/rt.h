@@ -205,6 +205,14 @@ int rt_primary_hits_f64(rt_scene* scene, const rt_camera* cam, uint32_t width, u
                         uint64_t seed, double time, uint32_t* prim_id, double* t, double* normal,
                         double* uv, uint8_t* front_face);
 
+/* The same query answered by the walk rt_render uses for this scene (the leaf list, or the ordered walk of
+ * the library's own SAH tree when every box is proven conservative; else the reference-order walk):
+ * lets a caller check, pixel for pixel, that the production walk picks the winner hittable.rs:400-412
+ * picks.  No counterpart in the reference beyond rt_primary_hits'.                                   */
+int rt_primary_hits_fast(rt_scene* scene, const rt_camera* cam, uint32_t width, uint32_t height,
+                         uint64_t seed, double time, uint32_t* prim_id, float* t, float* normal,
+                         float* uv, uint8_t* front_face);
+
 /* Replaces: the render closure main.rs:154-167 minus the divide and quantise.  accum_rgb is
  * a HOST array [h][w][3] that receives the SUM (not the mean) of this call's spp samples.  */
 int rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,

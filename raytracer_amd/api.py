@@ -120,14 +120,14 @@ class DeviceScene:
         except Exception:
             pass
 
-    def primary_hits(self, width, height, seed=1, time=0.0, f64=False, camera=None):
+    def primary_hits(self, width, height, seed=1, time=0.0, f64=False, camera=None, fast=False):
         dt = np.float64 if f64 else np.float32
         ids = np.zeros((height, width), dtype=np.uint32)
         t = np.zeros((height, width), dtype=dt)
         nrm = np.zeros((height, width, 3), dtype=dt)
         uv = np.zeros((height, width, 2), dtype=dt)
         ff = np.zeros((height, width), dtype=np.uint8)
-        fn = F.hip.rt_primary_hits_f64 if f64 else F.hip.rt_primary_hits
+        fn = F.hip.rt_primary_hits_f64 if f64 else (F.hip.rt_primary_hits_fast if fast else F.hip.rt_primary_hits)
         cam = camera if camera is not None else self.host.camera
         F.check_hip(fn(self._h, C.byref(cam), width, height, seed, time, _ptr(ids), _ptr(t), _ptr(nrm), _ptr(uv),
                        _ptr(ff)))

@@ -1116,12 +1116,14 @@ __global__ void __launch_bounds__(BLOCK, RT_SORTED_MIN_WAVES) render_sorted_kern
 }
 
 // world.hit() for the deterministic primary ray of every pixel: parity levels 1-2.
-template <typename R>
+// TRAV = 0: the reference's left-first walk; 1 / 2 (f32): the production walks (leaf list / ordered walk of the
+// SAH tree), so that their winner can be compared with the reference walk's pixel for pixel.
+template <typename R, int TRAV = 0>
 __global__ void __launch_bounds__(BLOCK) primary_kernel(SceneView<R> sc, CameraView<R> cam, uint32_t width,
                                                         uint32_t height, uint64_t seed, R time,
                                                         uint32_t* __restrict__ prim_id, R* __restrict__ t_out,
                                                         R* __restrict__ normal, R* __restrict__ uv,
-                                                        uint8_t* __restrict__ front_face) {
+                                                        uint8_t* __restrict__ front_face, uint32_t stack_depth) {
   extern __shared__ uint32_t lds_stack[];
   uint32_t* stack = lds_stack + threadIdx.x;
   uint32_t px, py;
@@ -1141,7 +1143,21 @@ __global__ void __launch_bounds__(BLOCK) primary_kernel(SceneView<R> sc, CameraV
   cnt.clear();
   R t;
   uint32_t best;
-  traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+  if constexpr (TRAV == TRAV_ORDERED) {
+    OrderedWalk walk;
+    bool more = walk.start(sc, ray);
+    while (more)
+      more = walk.step(sc, ray, R(0.001), rng, stack, reinterpret_cast<uint16_t*>(lds_stack + stack_depth * BLOCK) + threadIdx.x,
+                       (uint32_t)BLOCK, cnt);
+    t = walk.closest;
+    best = walk.best;
+  } else if constexpr (TRAV == TRAV_LINEAR) {
+    uint32_t k;
+    traverse_linear<false, true>(reinterpret_cast<const float*>(sc.linear_rec), sc.n_linear, ray, R(0.001), rng, t, k, cnt);
+    best = k == REF_NONE ? REF_NONE : sc.linear_rec[k * LIN_DWORDS + LIN_REF];
+  } else {
+    traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+  }
   HitRec<R> h;
   h.object = REF_NONE;
   h.normal = Vec3<R>(0, 0, 0);

@@ -92,8 +92,20 @@ hipError_t RT_CAT(launch_primary_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, cons
                                               uint8_t* front_face, LaunchShape shape, hipStream_t st) {
   dim3 grid(shape.tiles, 1, 1), block(BLOCK, 1, 1);
   size_t lds = (size_t)shape.stack_depth * BLOCK * sizeof(uint32_t);
-  hipLaunchKernelGGL((primary_kernel<RT_REAL>), grid, block, lds, st, sc, cam, width, height, seed, time, prim_id, t,
-                     normal, uv, front_face);
+#if RT_HAS_LINEAR
+  if (shape.trav == TRAV_ORDERED) {
+    hipLaunchKernelGGL((primary_kernel<RT_REAL, TRAV_ORDERED>), grid, block, lds + lds / 2, st, sc, cam, width, height, seed,
+                       time, prim_id, t, normal, uv, front_face, shape.stack_depth);
+    return hipGetLastError();
+  }
+  if (shape.trav == TRAV_LINEAR) {
+    hipLaunchKernelGGL((primary_kernel<RT_REAL, TRAV_LINEAR>), grid, block, lds, st, sc, cam, width, height, seed, time,
+                       prim_id, t, normal, uv, front_face, shape.stack_depth);
+    return hipGetLastError();
+  }
+#endif
+  hipLaunchKernelGGL((primary_kernel<RT_REAL, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, width, height, seed, time,
+                     prim_id, t, normal, uv, front_face, shape.stack_depth);
   return hipGetLastError();
 }
 

@@ -895,7 +895,7 @@ int render_to_host(rt_scene* s, const rt_camera* cam, const rt_params* p, R* h_a
 
 template <typename R>
 int primary_to_host(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t h, uint64_t seed, double time,
-                    uint32_t* prim_id, R* t, R* normal, R* uv, uint8_t* front_face) {
+                    uint32_t* prim_id, R* t, R* normal, R* uv, uint8_t* front_face, bool fast = false) {
   if (!s || !cam || !prim_id || !t || !normal) return fail(RT_ERR_BAD_ARG, "rt_primary_hits: null argument");
   if (w < 2 || h < 2) return fail(RT_ERR_BAD_ARG, "rt_primary_hits: image must be at least 2x2");
   HIP_TRY(hipSetDevice(s->device));
@@ -914,7 +914,9 @@ int primary_to_host(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t h, u
   HIP_TRY(alloc(n * 3 * sizeof(R), (void**)&d_n));
   if (uv) HIP_TRY(alloc(n * 2 * sizeof(R), (void**)&d_uv));
   if (front_face) HIP_TRY(alloc(n, (void**)&d_ff));
-  LaunchShape sh = make_shape(s, w, h, 1);
+  LaunchShape sh = make_shape(s, w, h, 1, fast && sizeof(R) == 4, cam, 0);
+  sh.tiles = ((w + 15) / 16) * ((h + 15) / 16);  // the primary kernel is tile-per-workgroup whatever the render shape
+  if (fast && (time < s->safe_t_lo || time > s->safe_t_hi)) sh.trav = 0;
   HIP_TRY(Side<R>::primary(Side<R>::get(s).view, to_camera<R>(*cam), w, h, seed, (R)time, d_id, d_t, d_n, d_uv, d_ff, sh,
                            nullptr));
   HIP_TRY(hipDeviceSynchronize());
@@ -937,6 +939,11 @@ int rt_primary_hits(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t h, u
 int rt_primary_hits_f64(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t h, uint64_t seed, double time,
                         uint32_t* prim_id, double* t, double* normal, double* uv, uint8_t* front_face) {
   return primary_to_host<double>(s, cam, w, h, seed, time, prim_id, t, normal, uv, front_face);
+}
+
+int rt_primary_hits_fast(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t h, uint64_t seed, double time,
+                         uint32_t* prim_id, float* t, float* normal, float* uv, uint8_t* front_face) {
+  return primary_to_host<float>(s, cam, w, h, seed, time, prim_id, t, normal, uv, front_face, true);
 }
 
 int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* p, float* accum, rt_stats* stats) {

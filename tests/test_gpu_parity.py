@@ -228,3 +228,35 @@ def test_sorted_kernel_experiment_renders_the_same_paths(earthmap):
     same = np.isclose(a, b, rtol=1e-4, atol=1e-5).all(axis=-1)
     assert same.mean() >= 0.97, same.mean()
     assert abs(a.sum() / b.sum() - 1.0) <= 0.005
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_production_walk_picks_the_reference_walks_primary_hit(name, earthmap):
+    """rt_primary_hits_fast answers the primary-ray query with the walk rt_render uses (leaf list, or the
+    ordered walk of the library's own SAH tree), rt_primary_hits with the reference-order walk of the
+    reference's tree.  Same f32 leaf tests, so the winner (object id), t, normal and front_face must be
+    IDENTICAL — the claim of DESIGN.md section 3.2 ("why the winner is the same"), including exact ties."""
+    hs, ds, os_, h, _ = _pair(name, earthmap)
+    for time in (0.0, 0.625):
+        for w in (W, 97):  # 97: ragged tiles
+            hh = max(2, int(w / SCENES[name][1]))
+            a = ds.primary_hits(w, hh, seed=3, time=time, fast=True)
+            b = ds.primary_hits(w, hh, seed=3, time=time)
+            assert np.array_equal(a[0], b[0]), f"{name}: {(a[0] != b[0]).sum()} ids differ"
+            hit = b[0] != 0xFFFFFFFF
+            assert np.array_equal(a[1][hit], b[1][hit])
+            assert np.array_equal(a[2][hit], b[2][hit]) and np.array_equal(a[4][hit], b[4][hit])
+
+
+def test_production_walk_primary_hits_at_one_million_spheres():
+    """The same identity at BASELINE config 4's scene size (10^6 spheres, SAH tree of 999 999 nodes,
+    1280x720 primary rays): every pixel's winner, t and normal equal the reference-order walk's."""
+    import raytracer_amd as R
+    hs = R.HostScene(7, 16.0 / 9.0, n=1000000)
+    ds = R.DeviceScene(hs, 0)
+    a = ds.primary_hits(1280, 720, seed=3, time=0.25, fast=True)
+    b = ds.primary_hits(1280, 720, seed=3, time=0.25)
+    assert np.array_equal(a[0], b[0]), f"{(a[0] != b[0]).sum()} ids differ"
+    hit = b[0] != 0xFFFFFFFF
+    assert hit.mean() > 0.5
+    assert np.array_equal(a[1][hit], b[1][hit]) and np.array_equal(a[2][hit], b[2][hit])
