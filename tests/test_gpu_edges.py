@@ -234,3 +234,29 @@ def test_full_size_cornell_properties():
     assert abs(float(other.sum()) / float(whole.sum()) - 1.0) < 1e-3
     d = (np.clip(other / 512, 0, 1) - np.clip(whole / 512, 0, 1))
     assert 0.01 < np.sqrt(np.mean(d * d)) < 0.06  # two independent 512-spp estimates: noise, not bias, not identity
+
+
+def test_scenes_come_and_go_without_leaking_device_memory():
+    import torch
+    import raytracer_amd as R
+    hs = R.HostScene(7, 16.0 / 9.0, n=20000)
+    ds = R.DeviceScene(hs, 0)
+    ds.render(32, 18, 1, 2)
+    ds.close()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for _ in range(20):
+        ds = R.DeviceScene(hs, 0)
+        ds.render(32, 18, 1, 2)
+        ds.primary_hits(32, 18)
+        ds.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < 8 << 20, f"{(free0 - free1) >> 20} MiB lost over 20 create/destroy cycles"
+    # two scenes alive at once render independently
+    a, b = R.DeviceScene(R.HostScene(6, 1.0), 0), R.DeviceScene(R.HostScene(5, 1.5), 0)
+    ia, _ = a.render(40, 40, 4, 5, seed=1)
+    ib, _ = b.render(40, 26, 4, 5, seed=1)
+    ia2, _ = a.render(40, 40, 4, 5, seed=1)
+    np.testing.assert_allclose(ia, ia2, rtol=1e-5, atol=1e-6)
+    assert ib.shape == (26, 40, 3)
