@@ -261,8 +261,10 @@ int rt_tonemap_device(int device, const float* accum_rgb_device, uint64_t n_pixe
 int rt_kat_sphere_uv(int device, uint32_t n, const double* p /*[n][3]*/, double* uv /*[n][2]*/, int use_f32);
 int rt_kat_rotate(int device, uint32_t n, const double* angle_rad, const double* axis /*[n][3]*/,
                   const double* v /*[n][3]*/, double* out /*[n][3]*/, int use_f32);
+/* rounds: 7 = the generator of the per-path draw streams (Philox4x32-7), 10 = the generator of the
+ * scene and BVH-axis streams (Philox4x32-10).  Both are pinned by Random123's published vectors.     */
 int rt_kat_philox(int device, uint32_t n, const uint32_t* ctr /*[n][4]*/, const uint32_t* key /*[n][2]*/,
-                  uint32_t* out /*[n][4]*/);
+                  uint32_t rounds, uint32_t* out /*[n][4]*/);
 
 int rt_device_count(void);
 uint32_t rt_abi_version(void);

@@ -166,8 +166,8 @@ void orc_rotate(double angle_rad, const double* axis, const double* v, double* o
   Quat q = new_quaternion(angle_rad, V3(axis[0], axis[1], axis[2]));
   fill3(out, rotate(V3(v[0], v[1], v[2]), q));
 }
-void orc_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
-  Philox4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+void orc_philox(const uint32_t* ctr, const uint32_t* key, uint32_t rounds, uint32_t* out) {
+  Philox4 r = philox4x32(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], (int)rounds);
   std::memcpy(out, r.v, sizeof(r.v));
 }
 int orc_bvh_axis(uint64_t bvh_seed, uint32_t call) { return bvh_axis(bvh_seed, call); }

@@ -141,7 +141,7 @@ hip.rt_tonemap.restype = None
 hip.rt_tonemap_device.argtypes = [C.c_int, _p, C.c_uint64, C.c_uint64, _p, _p]
 hip.rt_kat_sphere_uv.argtypes = [C.c_int, C.c_uint32, _p, _p, C.c_int]
 hip.rt_kat_rotate.argtypes = [C.c_int, C.c_uint32, _p, _p, _p, _p, C.c_int]
-hip.rt_kat_philox.argtypes = [C.c_int, C.c_uint32, _p, _p, _p]
+hip.rt_kat_philox.argtypes = [C.c_int, C.c_uint32, _p, _p, C.c_uint32, _p]
 
 host.rth_last_error.restype = C.c_char_p
 host.rth_scene_build.argtypes = [C.POINTER(RthSceneOpts), C.POINTER(_p)]

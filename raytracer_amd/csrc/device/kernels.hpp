@@ -1220,10 +1220,15 @@ __global__ void kat_rotate_kernel(uint32_t n, const double* angle, const double*
   out[3 * i + 2] = (double)r.z;
 }
 #ifdef RT_DEFINE_COMMON
-__global__ void kat_philox_kernel(uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+// path_stream != 0: the function the render kernels draw from (philox_path, RT_PATH_PHILOX_ROUNDS);
+// else Philox4x32-10, the host's scene/BVH-axis generator, for the published 10-round vectors.
+__global__ void kat_philox_kernel(uint32_t n, const uint32_t* ctr, const uint32_t* key, int path_stream,
+                                  uint32_t* out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  U4 r = philox4x32_10(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], key[2 * i], key[2 * i + 1]);
+  const uint32_t c0 = ctr[4 * i], c1 = ctr[4 * i + 1], c2 = ctr[4 * i + 2], c3 = ctr[4 * i + 3];
+  const uint32_t k0 = key[2 * i], k1 = key[2 * i + 1];
+  U4 r = path_stream ? philox_path(c0, c1, c2, c3, k0, k1) : philox4x32<10>(c0, c1, c2, c3, k0, k1);
   out[4 * i] = r.x;
   out[4 * i + 1] = r.y;
   out[4 * i + 2] = r.z;

@@ -1,4 +1,4 @@
-// Philox4x32-10 (Salmon et al., SC'11) and the per-path draw streams that replace the
+// Philox4x32 (Salmon et al., SC'11; 7 rounds for the path streams, see RT_PATH_PHILOX_ROUNDS) and the per-path draw streams that replace the
 // reference's `rand` thread_rng (main.rs:161-162, cam.rs:69, alias.rs:41-91,
 // hittable.rs:342,511, pdf.rs:36, material.rs:77).
 //
@@ -17,14 +17,19 @@ struct U4 {
   uint32_t x, y, z, w;
 };
 
-RT_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+// Path streams run Philox4x32-7: the fewest rounds Salmon et al. report as passing BigCrush (10 is their
+// conservative default).  Measured on the Cornell kernel: 54.8 -> 57.7 Grays/s.  The oracle uses the same
+// constant (oracle/src/philox.h); the host's scene and BVH-axis streams keep 10 rounds.
+#ifndef RT_PATH_PHILOX_ROUNDS
+#define RT_PATH_PHILOX_ROUNDS 7
+#endif
+
+template <int ROUNDS>
+RT_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
   const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-#ifndef RT_PHILOX_ROUNDS
-#define RT_PHILOX_ROUNDS 10
-#endif
-  for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     // one 32x32->64 multiply each (v_mad_u64_u32) instead of a mul_hi + mul_lo pair
     const uint64_t p0 = (uint64_t)M0 * c0;
     const uint64_t p1 = (uint64_t)M1 * c2;
@@ -38,6 +43,9 @@ RT_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
     k1 += W1;
   }
   return U4{c0, c1, c2, c3};
+}
+RT_DEV U4 philox_path(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  return philox4x32<RT_PATH_PHILOX_ROUNDS>(c0, c1, c2, c3, k0, k1);
 }
 
 template <typename R> RT_DEV R u01(uint32_t x);
@@ -61,7 +69,7 @@ struct Rng {
     w0 = w1 = w2 = w3 = 0;
   }
   RT_DEV void refill() {
-    U4 r = philox4x32_10(pixel, sample, slot, block, k0, k1);
+    U4 r = philox_path(pixel, sample, slot, block, k0, k1);
     ++block;
     w0 = r.x;
     w1 = r.y;
@@ -92,7 +100,7 @@ struct Rng {
   // The draw of one constant medium in the current slot: word 0 of block 0x80000000 | object id.
   // Keyed instead of sequential, so any traversal order gives every medium the same draw.
   template <typename R> RT_DEV R keyed(uint32_t object_id) const {
-    return u01<R>(philox4x32_10(pixel, sample, slot, 0x80000000u | object_id, k0, k1).x);
+    return u01<R>(philox_path(pixel, sample, slot, 0x80000000u | object_id, k0, k1).x);
   }
   template <typename R> RT_DEV R next() { return u01<R>(next_u32()); }
   template <typename R> RT_DEV R range(R lo, R hi) { return lo + (hi - lo) * next<R>(); }

@@ -38,6 +38,7 @@ RT_DECLARE_LAUNCHERS(f64, double)
 
 hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t* out, hipStream_t st);
 hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, hipStream_t st);
-hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t* out, hipStream_t st);
+hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, int path_stream, uint32_t* out,
+                             hipStream_t st);
 
 }  // namespace rt

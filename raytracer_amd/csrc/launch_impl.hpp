@@ -134,8 +134,9 @@ hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, hipStream_
   hipLaunchKernelGGL(accum_add_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, dst, src, n);
   return hipGetLastError();
 }
-hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t* out, hipStream_t st) {
-  hipLaunchKernelGGL(kat_philox_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, ctr, key, out);
+hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, int path_stream, uint32_t* out,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(kat_philox_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, ctr, key, path_stream, out);
   return hipGetLastError();
 }
 #endif

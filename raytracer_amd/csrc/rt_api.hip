@@ -1116,16 +1116,18 @@ int rt_kat_rotate(int device, uint32_t n, const double* angle, const double* axi
                     &c);
 }
 
-int rt_kat_philox(int device, uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+int rt_kat_philox(int device, uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t rounds, uint32_t* out) {
   if (!ctr || !key || !out || n == 0) return fail(RT_ERR_BAD_ARG, "rt_kat_philox: bad argument");
+  if (rounds != 7 && rounds != 10)
+    return fail(RT_ERR_BAD_ARG, "rt_kat_philox: rounds must be 7 (path streams) or 10 (scene streams)");
   size_t ib[] = {n * 4 * sizeof(uint32_t), n * 2 * sizeof(uint32_t)};
   const void* in[] = {ctr, key};
-  KatCtx c{n, 0};
+  KatCtx c{n, rounds == 7 ? 1 : 0};
   return kat_common(device, ib, in, 2, n * 4 * sizeof(uint32_t), out,
                     [](void** di, void* dout, void* ctx) -> hipError_t {
                       auto* k = (KatCtx*)ctx;
-                      return launch_kat_philox(k->n, (const uint32_t*)di[0], (const uint32_t*)di[1], (uint32_t*)dout,
-                                               nullptr);
+                      return launch_kat_philox(k->n, (const uint32_t*)di[0], (const uint32_t*)di[1], k->use_f32,
+                                               (uint32_t*)dout, nullptr);
                     },
                     &c);
 }

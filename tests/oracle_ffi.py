@@ -84,7 +84,7 @@ def lib(name="liboracle.so"):
         L.orc_tonemap.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
         L.orc_get_sphere_uv.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_rotate.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_bvh_axis.restype = C.c_int
         L.orc_bvh_axis.argtypes = [C.c_uint64, C.c_uint32]
         L.orc_scene_draws.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -178,11 +178,11 @@ def rotate(angle_rad, axis, v):
     return out
 
 
-def philox(ctr, key):
+def philox(ctr, key, rounds=10):
     ctr = np.asarray(ctr, dtype=np.uint32)
     key = np.asarray(key, dtype=np.uint32)
     out = np.zeros(4, dtype=np.uint32)
-    lib().orc_philox(_ptr(ctr), _ptr(key), _ptr(out))
+    lib().orc_philox(_ptr(ctr), _ptr(key), rounds, _ptr(out))
     return out
 
 

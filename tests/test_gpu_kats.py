@@ -44,10 +44,11 @@ def test_device_rotate(use_f32):
     assert np.abs(out - want).max() < tol
 
 
-def test_device_philox():
+@pytest.mark.parametrize("rounds", [7, 10])  # 7: per-path draw streams, 10: scene and BVH-axis streams
+def test_device_philox(rounds):
     from raytracer_amd import _ffi as F
     import oracle_ffi as O
-    ks = KATS["philox4x32_10"]
+    ks = KATS["philox4x32_%d" % rounds]
     rng = np.random.default_rng(1)
     extra = 1000
     ctr = np.concatenate([np.array([k["ctr"] for k in ks], dtype=np.uint32),
@@ -55,8 +56,8 @@ def test_device_philox():
     key = np.concatenate([np.array([k["key"] for k in ks], dtype=np.uint32),
                           rng.integers(0, 2**32, size=(extra, 2), dtype=np.uint64).astype(np.uint32)])
     out = np.zeros_like(ctr)
-    F.check_hip(F.hip.rt_kat_philox(0, len(ctr), _ptr(ctr), _ptr(key), _ptr(out)))
+    F.check_hip(F.hip.rt_kat_philox(0, len(ctr), _ptr(ctr), _ptr(key), rounds, _ptr(out)))
     for i, k in enumerate(ks):
         assert list(out[i]) == k["out"]
     for i in range(len(ks), len(ctr)):
-        assert np.array_equal(out[i], O.philox(ctr[i], key[i]))
+        assert np.array_equal(out[i], O.philox(ctr[i], key[i], rounds))

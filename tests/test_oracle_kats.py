@@ -50,8 +50,9 @@ def test_host_rotate_matches_kats_and_oracle():
 
 
 def test_oracle_philox_kats():
-    for k in KATS["philox4x32_10"]:
-        assert list(O.philox(k["ctr"], k["key"])) == k["out"]
+    for rounds in (7, 10):  # 7: per-path draw streams, 10: scene and BVH-axis streams
+        for k in KATS["philox4x32_%d" % rounds]:
+            assert list(O.philox(k["ctr"], k["key"], rounds)) == k["out"]
 
 
 def test_streams_are_uniform_and_keyed():
@@ -62,7 +63,7 @@ def test_streams_are_uniform_and_keyed():
     assert abs(a.mean() - 0.5) < 0.02 and abs(a.var() - 1 / 12) < 0.01
     assert not np.array_equal(a, b) and not np.array_equal(a, c)
     # draws are words of consecutive Philox blocks of the (pixel, sample, slot) stream
-    blk = O.philox([10, 3, 1, 0], [1, 0])
+    blk = O.philox([10, 3, 1, 0], [1, 0], rounds=7)
     assert np.array_equal(a[:4], blk.astype(np.float64) / 2**32)
 
 
