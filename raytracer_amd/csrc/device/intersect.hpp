@@ -612,7 +612,10 @@ template <typename R> RT_DEV Vec3<R> cube_normal(Vec3<R> rel) {
   if (rel.y > R(1) - eps) return Vec3<R>(0, -1, 0);
   if (rel.z < eps) return Vec3<R>(0, 0, 1);
   if (rel.z > R(1) - eps) return Vec3<R>(0, 0, -1);
-  return normalize(Vec3<R>(R(0.5), R(0.5), R(0.5)));
+  if constexpr (sizeof(R) == 4)  // a literal: the compiler does not fold the hardware rsq and keeps (then spills) a register for it
+    return Vec3<R>(0.57735026f, 0.57735026f, 0.57735026f);
+  else
+    return normalize(Vec3<R>(R(0.5), R(0.5), R(0.5)));
 }
 
 template <typename R>

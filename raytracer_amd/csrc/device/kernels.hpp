@@ -712,6 +712,10 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
   const Light<R>* lights = sc.n_lights <= LDS_MAX_LIGHTS ? s_lights : sc.lights;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const Vec3<R> background(sc.background[0], sc.background[1], sc.background[2]);
+  // wave-uniform reciprocals of main.rs:161-163, pinned to scalar registers (the compiler keeps the result
+  // of a VALU rcp in a vector register otherwise, and at 96 VGPRs that register is spilled to scratch)
+  const R inv_wm1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rrcp((R)(a.width - 1)))));
+  const R inv_hm1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rrcp((R)(a.height - 1)))));
 
   Cnt<STATS> cnt;
   cnt.clear();
@@ -727,8 +731,13 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
   uint32_t depth_left = 0, slot = 0;
   Rng rng;
   rng.init(a.seed, 0, 0);
+#ifdef RT_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
 
   for (;;) {
+    RT_STAMP(0);  // loop tail + re-convergence
     // (0) lanes that have finished their pixel's samples of a unit move on to the wave's next unit
     const bool needy = !alive && s == s_end && !lane_done;
     if (__ballot(needy)) {  // wave-uniform
@@ -783,6 +792,7 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
         }  // else: the ring is full; try again once the slowest lane has moved on
       }
     }
+    RT_STAMP(1);  // unit hand-over
     if (!alive) {
       if (s == s_end) {
         if (lane_done) break;
@@ -793,8 +803,8 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
       rng.begin(0);
       R ju = rng.next<R>();
       R jv = rng.next<R>();
-      R u = rdiv((R)px + ju, (R)(a.width - 1));                  // main.rs:161
-      R v = rdiv((R)(a.height - py - 1) + jv, (R)(a.height - 1));  // main.rs:162-163
+      R u = ((R)px + ju) * inv_wm1;                  // main.rs:161
+      R v = ((R)(a.height - py - 1) + jv) * inv_hm1;  // main.rs:162-163
       ray = camera_ray(cam, u, v, rng);
       thr = Vec3<R>(1, 1, 1);
       L = Vec3<R>(0, 0, 0);
@@ -802,14 +812,17 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
       slot = 1;
       alive = true;
     }
+    RT_STAMP(2);  // camera ray
     rng.begin(slot);
     cnt.template inc<ST_RAYS>();
+    RT_STAMP(3);  // bounce Philox block
     R t;
     uint32_t best;
     if (sc.linear_has_media)  // wave-uniform
       traverse_linear<STATS, true>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
     else
       traverse_linear<STATS, false>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+    RT_STAMP(4);  // leaf-list walk
     bool cont;
     if (best == REF_NONE) {  // main.rs:104
       cnt.template inc<ST_MISSES>();
@@ -820,8 +833,10 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
       HitRec<R> h;
       Material<R> mat;
       lin_hit_record(sc, s_lin + best * LIN_DWORDS, ray, t, h, mat);
+      RT_STAMP(5);  // hit record
       cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
     }
+    RT_STAMP(6);  // shade (or miss)
     ++slot;
     --depth_left;
     if (depth_left == 0) cont = false;  // the next ray_color call would return 0
@@ -833,6 +848,10 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
       alive = false;
     }
   }
+#ifdef RT_STAMPS
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&stats->stamp[i], stamp_acc[i]);
+#endif
   flush_stats(cnt, stats);
   uint32_t nf = wave_sum(nonfinite);
   if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&stats->v[ST_NONFINITE], (unsigned long long)nf);
