@@ -59,6 +59,10 @@ typedef struct rth_render_opts {   /* = struct Opts, main.rs:28-49, plus what ma
 int rth_render(const rth_render_opts* opts, uint8_t* rgb8, float* accum, uint32_t* height_out, rt_stats* stats);
 uint32_t rth_image_height(uint32_t image_width, double aspect_ratio); /* main.rs:112 */
 
+/* Replaces image.save(opts.output) (main.rs:176) for the reference's default format: an 8-bit RGB PNG
+ * (stored deflate blocks; decodes to exactly rgb8).  rgb8 is [height][width][3].                      */
+int rth_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+
 /* Host-side known-answer hooks for the two functions the reference's tests pin. */
 void rth_rotate(double angle_rad, const double axis[3], const double v[3], double out[3]);
 int rth_bvh_axis(uint64_t bvh_seed, uint32_t call);

@@ -102,7 +102,8 @@ RT_SYMBOLS = [
 ]
 RTH_SYMBOLS = [
     "rth_scene_build", "rth_scene_free", "rth_scene_desc", "rth_scene_camera", "rth_scene_object_count",
-    "rth_scene_bvh_calls", "rth_camera_new", "rth_render", "rth_image_height", "rth_rotate", "rth_bvh_axis",
+    "rth_scene_bvh_calls", "rth_camera_new", "rth_render", "rth_image_height", "rth_write_png", "rth_rotate",
+    "rth_bvh_axis",
     "rth_last_error",
 ]
 
@@ -160,6 +161,7 @@ host.rth_camera_new.argtypes = [_p, _p, _p, C.c_double, C.c_double, C.c_double, 
 host.rth_render.argtypes = [C.POINTER(RthRenderOpts), _p, _p, _u32p, C.POINTER(RtStats)]
 host.rth_image_height.argtypes = [C.c_uint32, C.c_double]
 host.rth_image_height.restype = C.c_uint32
+host.rth_write_png.argtypes = [C.c_char_p, _p, C.c_uint32, C.c_uint32]
 host.rth_rotate.argtypes = [C.c_double, _p, _p, _p]
 host.rth_rotate.restype = None
 host.rth_bvh_axis.argtypes = [C.c_uint64, C.c_uint32]

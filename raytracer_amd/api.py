@@ -28,6 +28,27 @@ def load_earthmap():
         return np.ascontiguousarray(z["rgb8"])
 
 
+def write_earthmap_ppm(path):
+    """The earth texture as a binary PPM (P6): what the `raytracer` command line reads with --earthmap
+    (default assets/earthmap.ppm) where the reference opens assets/earthmap.jpg (scenes.rs:126)."""
+    rgb8 = load_earthmap()
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb8.shape[1], rgb8.shape[0]))
+        f.write(rgb8.tobytes())
+
+
+def write_png(path, rgb8):
+    """image.save(path) of main.rs:176 for an RGB8 image [h][w][3] (8-bit RGB PNG, stored deflate)."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    if rgb8.ndim != 3 or rgb8.shape[2] != 3:
+        raise ValueError("rgb8 must be [h][w][3]")
+    F.check_host(F.host.rth_write_png(os.fsencode(path), _ptr(rgb8), rgb8.shape[1], rgb8.shape[0]))
+
+
+CLI = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "raytracer")  # main.rs:28-49, 107-178
+
+
 def image_height(image_width, aspect_ratio):
     """main.rs:112: `(image_width as f64 / aspect_ratio) as u32` (truncation)."""
     return int(F.host.rth_image_height(int(image_width), float(aspect_ratio)))

@@ -1,0 +1,245 @@
+// `raytracer` — the reference's command line (struct Opts + main(), main.rs:28-49, 107-178) over
+// librt_host.so / librt_hip.so: same options, defaults, stdout lines and output file; the render runs on
+// the GPU through include/rt.h.  Options after the reference's own are extensions and say so in --help.
+//
+// Differences a user can see: the PNG is written with stored deflate blocks (same pixels, larger file);
+// the earth texture is read from a binary PPM (`--earthmap`, default assets/earthmap.ppm, where the
+// reference opens assets/earthmap.jpg, scenes.rs:126) because no JPEG decoder is linked —
+// `python -c "import raytracer_amd as R; R.write_earthmap_ppm('assets/earthmap.ppm')"` writes it; the
+// reference's panics (bad numbers, unwritable output) are error messages with exit status 2 / 1.
+#include <cctype>
+#include <cerrno>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/rt_host.h"
+
+namespace {
+
+struct Opts {  // main.rs:28-49
+  std::string output = "renders/image.png";
+  uint32_t scene = 3;
+  uint32_t image_width = 1200;
+  double aspect_ratio = 1.5;
+  uint32_t samples_per_pixel = 500;
+  uint32_t max_depth = 5;
+  // extensions
+  int device = 0;
+  uint64_t seed = 1, scene_seed = 5, bvh_seed = 7;
+  uint32_t n = 0;
+  std::string earthmap = "assets/earthmap.ppm";
+};
+
+const char* USAGE =
+    "raytracer 1.0\nBEat\nA cool raytracer!\n\n"
+    "USAGE:\n    raytracer [OPTIONS]\n\n"
+    "FLAGS:\n"
+    "    -h, --help       Prints help information\n"
+    "    -V, --version    Prints version information\n\n"
+    "OPTIONS:\n"
+    "    -a, --aspect-ratio <aspect-ratio>              [default: 1.5]\n"
+    "    -i, --image-width <image-width>                [default: 1200]\n"
+    "        --max-depth <max-depth>                    [default: 5]\n"
+    "    -o, --output <output>                          Sets an output file to render too [default: renders/image.png]\n"
+    "        --samples-per-pixel <samples-per-pixel>    [default: 500]\n"
+    "    -s, --scene <scene>                            [default: 3]\n"
+    "\nEXTENSIONS (not in the reference):\n"
+    "        --device <n>          GPU to render on [default: 0]\n"
+    "        --seed <n>            Philox key of the per-path draws [default: 1]\n"
+    "        --scene-seed <n>      scene generator seed (scenes.rs:64 uses 5) [default: 5]\n"
+    "        --bvh-seed <n>        BVH split-axis stream [default: 7]\n"
+    "        --n <n>               scene 7 (bvh_stress): number of spheres\n"
+    "        --earthmap <file>     binary PPM (P6, maxval 255) of the earth texture, scenes 2, 4, 8\n"
+    "                              [default: assets/earthmap.ppm]\n"
+    "    scenes: 0 random_scene, 1 two_spheres, 2 earth, 3 simple_light, 4 cube_scene, 6 cornell_box,\n"
+    "            7 bvh_stress, 8 final_scene, anything else small_scene (main.rs:117-124)\n";
+
+[[noreturn]] void usage_error(const std::string& msg) {
+  std::fprintf(stderr, "error: %s\n\nUSAGE:\n    raytracer [OPTIONS]\n\nFor more information try --help\n", msg.c_str());
+  std::exit(2);
+}
+
+bool parse_u64(const std::string& s, uint64_t max, uint64_t& out) {
+  if (s.empty() || s[0] == '-' || s[0] == '+') return false;
+  char* end = nullptr;
+  errno = 0;
+  unsigned long long v = std::strtoull(s.c_str(), &end, 10);
+  if (errno || *end || v > max) return false;
+  out = v;
+  return true;
+}
+bool parse_f64(const std::string& s, double& out) {
+  if (s.empty()) return false;
+  char* end = nullptr;
+  out = std::strtod(s.c_str(), &end);
+  return *end == 0;
+}
+
+// P6 reader: "P6 <w> <h> 255\n" + w*h*3 bytes, '#' comments allowed in the header
+bool read_ppm(const std::string& path, std::vector<uint8_t>& texels, uint32_t& w, uint32_t& h) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  auto token = [&](std::string& t) {
+    t.clear();
+    int c;
+    for (;;) {
+      c = std::fgetc(f);
+      if (c == '#') {
+        while (c != '\n' && c != EOF) c = std::fgetc(f);
+      } else if (c == EOF || !std::isspace(c)) {
+        break;
+      }
+    }
+    while (c != EOF && !std::isspace(c)) {
+      t.push_back((char)c);
+      c = std::fgetc(f);
+    }
+    return !t.empty();
+  };
+  std::string magic, sw, sh, smax;
+  uint64_t vw = 0, vh = 0, vmax = 0;
+  bool ok = token(magic) && magic == "P6" && token(sw) && token(sh) && token(smax) && parse_u64(sw, 1u << 16, vw) &&
+            parse_u64(sh, 1u << 16, vh) && parse_u64(smax, 255, vmax) && vmax == 255 && vw > 0 && vh > 0;
+  if (ok) {
+    texels.resize((size_t)vw * vh * 3);
+    ok = std::fread(texels.data(), 1, texels.size(), f) == texels.size();
+    w = (uint32_t)vw;
+    h = (uint32_t)vh;
+  }
+  std::fclose(f);
+  return ok;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Opts o;
+  for (int i = 1; i < argc; ++i) {
+    std::string arg = argv[i], name = arg, value;
+    bool have_value = false;
+    if (arg.rfind("--", 0) == 0) {
+      const size_t eq = arg.find('=');
+      if (eq != std::string::npos) {
+        name = arg.substr(0, eq);
+        value = arg.substr(eq + 1);
+        have_value = true;
+      }
+    } else if (arg.size() > 2 && arg[0] == '-') {  // -i800
+      name = arg.substr(0, 2);
+      value = arg.substr(2);
+      if (!value.empty() && value[0] == '=') value.erase(0, 1);
+      have_value = true;
+    }
+    if (name == "-h" || name == "--help") {
+      std::fputs(USAGE, stdout);
+      return 0;
+    }
+    if (name == "-V" || name == "--version") {
+      std::puts("raytracer 1.0");
+      return 0;
+    }
+    auto need = [&]() -> const std::string& {
+      if (!have_value) {
+        if (i + 1 >= argc) usage_error("The argument '" + name + " <value>' requires a value but none was supplied");
+        value = argv[++i];
+        have_value = true;
+      }
+      return value;
+    };
+    auto u32 = [&](uint32_t& dst) {
+      uint64_t v;
+      if (!parse_u64(need(), 0xFFFFFFFFull, v)) usage_error("Invalid value for '" + name + "': '" + value + "' is not a u32");
+      dst = (uint32_t)v;
+    };
+    auto u64 = [&](uint64_t& dst) {
+      if (!parse_u64(need(), ~0ull, dst)) usage_error("Invalid value for '" + name + "': '" + value + "' is not a u64");
+    };
+    if (name == "-o" || name == "--output") {
+      o.output = need();
+    } else if (name == "-s" || name == "--scene") {
+      u32(o.scene);
+    } else if (name == "-i" || name == "--image-width") {
+      u32(o.image_width);
+    } else if (name == "-a" || name == "--aspect-ratio") {
+      if (!parse_f64(need(), o.aspect_ratio)) usage_error("Invalid value for '" + name + "': '" + value + "' is not a float");
+    } else if (name == "--samples-per-pixel") {
+      u32(o.samples_per_pixel);
+    } else if (name == "--max-depth") {
+      u32(o.max_depth);
+    } else if (name == "--device") {
+      uint32_t d = 0;
+      u32(d);
+      o.device = (int)d;
+    } else if (name == "--seed") {
+      u64(o.seed);
+    } else if (name == "--scene-seed") {
+      u64(o.scene_seed);
+    } else if (name == "--bvh-seed") {
+      u64(o.bvh_seed);
+    } else if (name == "--n") {
+      u32(o.n);
+    } else if (name == "--earthmap") {
+      o.earthmap = need();
+    } else {
+      usage_error("Found argument '" + arg + "' which wasn't expected, or isn't valid in this context");
+    }
+  }
+
+  const uint32_t image_width = o.image_width;
+  const uint32_t image_height = rth_image_height(image_width, o.aspect_ratio);  // main.rs:112
+  std::printf("%u %u\n", image_width, image_height);                            // main.rs:114
+  std::fflush(stdout);
+  if (image_width < 2 || image_height < 2) {  // (image_width - 1) as f64 divides by zero / ImageBuffer of nothing
+    std::fprintf(stderr, "error: the image must be at least 2x2 pixels (got %ux%u)\n", image_width, image_height);
+    return 1;
+  }
+
+  rth_render_opts ro;
+  std::memset(&ro, 0, sizeof(ro));
+  ro.scene.scene_id = (int32_t)(o.scene > 0x7FFFFFFFu ? 0x7FFFFFFF : o.scene);
+  ro.scene.rotate_bbox = -1;
+  ro.scene.aspect_ratio = o.aspect_ratio;
+  ro.scene.scene_seed = o.scene_seed;
+  ro.scene.bvh_seed = o.bvh_seed;
+  ro.scene.n = o.n;
+  std::vector<uint8_t> texels;
+  if (o.scene == 2 || o.scene == 4 || o.scene == 8) {  // Texture::new_image (texture.rs:25-31, scenes.rs:126)
+    if (!read_ppm(o.earthmap, texels, ro.scene.tex_width, ro.scene.tex_height)) {
+      std::fprintf(stderr,
+                   "error: scene %u needs the earth texture: cannot read '%s' as a binary PPM (P6, maxval 255).\n"
+                   "       write it with: python -c \"import raytracer_amd as R; R.write_earthmap_ppm('assets/earthmap.ppm')\"\n",
+                   o.scene, o.earthmap.c_str());
+      return 1;
+    }
+    ro.scene.texels = texels.data();
+  }
+  ro.image_width = image_width;
+  ro.samples_per_pixel = o.samples_per_pixel;
+  ro.max_depth = o.max_depth;
+  ro.device = o.device;
+  ro.seed = o.seed;
+
+  std::vector<uint8_t> rgb8((size_t)image_width * image_height * 3);
+  rt_stats st;
+  std::memset(&st, 0, sizeof(st));
+  uint32_t h_out = 0;
+  const auto now = std::chrono::steady_clock::now();  // main.rs:153
+  if (rth_render(&ro, rgb8.data(), nullptr, &h_out, &st) != RT_OK) {
+    std::fprintf(stderr, "error: %s\n", rth_last_error());
+    return 1;
+  }
+  const float secs = std::chrono::duration<float>(std::chrono::steady_clock::now() - now).count();
+  std::printf("Rendered in %g seconds\n", (double)secs);  // main.rs:175
+  std::fprintf(stderr, "(%llu rays, %.1f ms in kernels, %.1f Mrays/s)\n", (unsigned long long)st.rays, st.kernel_ms,
+               st.kernel_ms > 0 ? (double)st.rays / st.kernel_ms * 1e-3 : 0.0);
+  if (rth_write_png(o.output.c_str(), rgb8.data(), image_width, image_height) != RT_OK) {  // main.rs:176
+    std::fprintf(stderr, "error: %s\n", rth_last_error());
+    return 1;
+  }
+  std::puts("Created image!");  // main.rs:177
+  return 0;
+}

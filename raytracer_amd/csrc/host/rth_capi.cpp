@@ -5,6 +5,7 @@
 
 #include "../../../include/rt_host.h"
 #include "rth.hpp"
+#include "png_write.hpp"
 
 using namespace rth;
 
@@ -26,6 +27,14 @@ struct rth_scene {
 extern "C" {
 
 const char* rth_last_error(void) { return g_err.c_str(); }
+
+// image.save(path) of main.rs:176 for an RGB8 image (PNG only: the reference's default output is a .png).
+int rth_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+  if (!path || !rgb8 || width == 0 || height == 0) return fail(RT_ERR_BAD_ARG, "rth_write_png: bad argument");
+  if (!rth::write_file(path, rth::encode_png_rgb8(rgb8, width, height)))
+    return fail(RT_ERR_BAD_ARG, std::string("rth_write_png: cannot write ") + path);
+  return RT_OK;
+}
 
 uint32_t rth_image_height(uint32_t image_width, double aspect_ratio) {
   double h = (double)image_width / aspect_ratio;  // `as u32` truncates and saturates

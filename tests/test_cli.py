@@ -1,0 +1,87 @@
+"""The reference's command line (struct Opts + main(), main.rs:28-49, 107-178) and its image.save."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import raytracer_amd as R
+
+
+def run(*args, cwd=None):
+    return subprocess.run([R.CLI, *args], capture_output=True, text=True, cwd=cwd, timeout=300)
+
+
+def test_help_lists_the_reference_options_and_defaults():
+    p = run("--help")
+    assert p.returncode == 0
+    for flag, default in (("-o, --output <output>", "renders/image.png"), ("-s, --scene <scene>", "3"),
+                          ("-i, --image-width <image-width>", "1200"), ("-a, --aspect-ratio <aspect-ratio>", "1.5"),
+                          ("--samples-per-pixel <samples-per-pixel>", "500"), ("--max-depth <max-depth>", "5")):
+        line = [l for l in p.stdout.splitlines() if flag in l]
+        assert line and f"[default: {default}]" in line[0], flag
+    assert run("-V").stdout.strip() == "raytracer 1.0"  # #[clap(version = "1.0")]
+
+
+@pytest.mark.parametrize("args", [["--bogus"], ["-i", "abc"], ["--scene"], ["-a", "x"], ["--max-depth", "-1"]])
+def test_bad_arguments_exit_2_like_clap(args):
+    p = run(*args)
+    assert p.returncode == 2 and p.stderr.startswith("error:") and p.stdout == ""
+
+
+def test_degenerate_image_is_an_error_not_a_crash(tmp_path):
+    p = run("-i", "1", "-o", str(tmp_path / "x.png"))
+    assert p.returncode == 1 and p.stdout.splitlines()[0] == "1 0"  # main.rs:114 prints before anything else
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (23, 37), (200, 300)])  # the last one needs several stored blocks
+def test_png_roundtrip(tmp_path, shape):
+    rgb8 = np.random.default_rng(shape[0]).integers(0, 256, size=shape + (3,), dtype=np.uint8)
+    path = str(tmp_path / "img.png")
+    R.write_png(path, rgb8)
+    with Image.open(path) as im:
+        assert im.mode == "RGB" and im.size == (shape[1], shape[0])
+        assert np.array_equal(np.asarray(im), rgb8)
+
+
+def test_png_errors(tmp_path):
+    with pytest.raises(Exception):
+        R.write_png(str(tmp_path / "no_such_dir" / "img.png"), np.zeros((2, 2, 3), np.uint8))  # image.save(..).unwrap()
+    with pytest.raises(ValueError):
+        R.write_png(str(tmp_path / "img.png"), np.zeros((2, 2), np.uint8))
+
+
+def test_earthmap_ppm(tmp_path):
+    path = str(tmp_path / "assets" / "earthmap.ppm")
+    R.write_earthmap_ppm(path)
+    with Image.open(path) as im:
+        assert np.array_equal(np.asarray(im), R.load_earthmap())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", [5, 2])
+def test_cli_renders_what_the_api_renders(tmp_path, scene):
+    if scene == 2:
+        R.write_earthmap_ppm(str(tmp_path / "assets" / "earthmap.ppm"))
+    os.makedirs(tmp_path / "renders")
+    args = ["-s", str(scene), "-i", "96", "--samples-per-pixel=16", "--max-depth", "5"]
+    p = run(*args, cwd=str(tmp_path))  # default output renders/image.png, default aspect 1.5
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.splitlines()
+    assert lines[0] == "96 64" and lines[1].startswith("Rendered in ") and lines[1].endswith(" seconds")
+    assert lines[2] == "Created image!"
+    with Image.open(tmp_path / "renders" / "image.png") as im:
+        got = np.asarray(im).astype(np.int32)
+    want, _, _ = R.render(scene=scene, image_width=96, aspect_ratio=1.5, samples_per_pixel=16, max_depth=5)
+    # same draws; the leaf-list kernel sums a pixel's units with float atomics, so a channel may land on
+    # the other side of a quantisation step
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_cli_missing_texture_and_missing_directory(tmp_path):
+    p = run("-s", "2", "-i", "32", "--samples-per-pixel", "1", cwd=str(tmp_path))
+    assert p.returncode == 1 and "earth texture" in p.stderr
+    p = run("-s", "5", "-i", "32", "--samples-per-pixel", "1", cwd=str(tmp_path))  # no renders/ directory
+    assert p.returncode == 1 and "cannot write" in p.stderr and "Created image!" not in p.stdout
