@@ -295,6 +295,81 @@ inline void final_scene(SceneDef& s, const SceneSpec& spec) {
   s.rotate_bbox = RotateBBox::Correct;
 }
 
+// Scene 9, "mixed_scene": not a reference scene and not a benchmark config — a seeded generator of feature
+// COMBINATIONS for the parity tests (every primitive kind under every wrapper nesting the flattener accepts,
+// every material and texture kind, one or several lights incl. a non-emitting one, both Rotate-bbox modes).
+// The host layer has its own copy (rth_scenes.cpp) written against the same draw list:
+//   per object, in order: shape class, material class, x, y, z, size, angle, axis, a1, a2, a3, fuzz.
+inline void mixed_scene(SceneDef& s, uint64_t seed, uint32_t n) {
+  Rng rng = scene_rng(seed, 0);
+  // the ground's top face is NOT at y = 0: a checker (sin(10 y)) on a plane at a zero of the sine picks its
+  // colour from the rounding noise of p.y, differently in every arithmetic
+  s.world.push_back(Hittable::new_cube(V3(-40.0, -1.1, -40.0), V3(40.0, -0.1, 40.0),
+                                       Material::lambertian_tex(Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9)))));
+  for (uint32_t i = 0; i < n; ++i) {
+    const int shape = (int)(rng.next_f64() * 9.0);
+    const int mat = (int)(rng.next_f64() * 7.0);
+    const double x = rng.range(-9.0, 9.0);
+    const double y = rng.range(0.4, 3.5);
+    const double z = rng.range(-9.0, 9.0);
+    const double sz = rng.range(0.25, 0.9);
+    const double angle = to_radians(rng.range(-60.0, 60.0));
+    const int axis_k = (int)(rng.next_f64() * 3.0);
+    const double a1 = rng.next_f64();
+    const double a2 = rng.next_f64();
+    const double a3 = rng.next_f64();
+    const double fuzz = rng.range(0.0, 0.5);
+    const V3 axis(axis_k == 0 ? 1.0 : 0.0, axis_k == 1 ? 1.0 : 0.0, axis_k == 2 ? 1.0 : 0.0);
+    const V3 c(x, y, z), col(a1, a2, a3), half(sz, sz, sz);
+    Material m;
+    switch (mat) {
+      case 0: m = Material::lambertian(col); break;
+      case 1: m = Material::lambertian_tex(Texture::checker_color(col, V3(0.9, 0.9, 0.9))); break;
+      case 2: m = Material::lambertian_tex(Texture::normal()); break;
+      case 3: m = Material::lambertian_tex(Texture::uv()); break;
+      case 4: m = Material::metal(V3(0.5 + 0.5 * a1, 0.5 + 0.5 * a2, 0.5 + 0.5 * a3), fuzz); break;
+      case 5: m = Material::dielectric(1.5); break;
+      default: m = Material::isotropic(col); break;
+    }
+    const double density = 0.5 + 2.0 * a2;
+    const V3 zero(0.0, 0.0, 0.0);
+    switch (shape) {
+      case 0: s.world.push_back(Hittable::new_sphere(c, sz, m)); break;
+      case 1: s.world.push_back(Hittable::new_moving_sphere(c, c + V3(0.0, 0.5 * a1, 0.0), 0.0, 1.0, sz, m)); break;
+      case 2: s.world.push_back(Hittable::new_cube(c - half, c + half, m)); break;
+      case 3: s.world.push_back(Hittable::new_rotate(Hittable::new_cube(c - half, c + half, m), angle, axis)); break;
+      case 4:
+        s.world.push_back(Hittable::new_translate(Hittable::new_rotate(Hittable::new_cube(zero - half, half, m), angle, axis), c));
+        break;
+      case 5:
+        s.world.push_back(Hittable::new_translate(Hittable::new_rotate(Hittable::new_sphere(zero, sz, m), angle, axis), c));
+        break;
+      case 6: s.world.push_back(Hittable::new_constant_medium(Hittable::new_sphere(c, 1.5 * sz, m), density, col)); break;
+      case 7:
+        s.world.push_back(Hittable::new_constant_medium(
+            Hittable::new_translate(Hittable::new_rotate(Hittable::new_cube(zero - half, half, m), angle, axis), c), density, col));
+        break;
+      default:
+        s.world.push_back(
+            Hittable::new_translate(Hittable::new_constant_medium(Hittable::new_sphere(zero, 1.5 * sz, m), density, col), c));
+        break;
+    }
+  }
+  auto lamp_a = [] { return Hittable::new_sphere(V3(-3.0, 7.0, 2.0), 1.0, Material::diffuse_light(V3(6.0, 6.0, 6.0))); };
+  auto lamp_b = [] { return Hittable::new_sphere(V3(4.0, 6.0, -3.0), 0.7, Material::diffuse_light(V3(9.0, 8.0, 7.0))); };
+  s.world.push_back(lamp_a());
+  s.world.push_back(lamp_b());
+  s.lights.push_back(lamp_a());
+  if (seed % 4 != 1) s.lights.push_back(lamp_b());  // else a single light: lights.pop() of main.rs:129
+  if (seed % 3 == 0) {                               // a "light" that emits nothing, as in simple_light (scenes.rs:139-143)
+    s.world.push_back(Hittable::new_sphere(V3(0.0, 1.0, 5.0), 0.5, Material::dielectric(1.5)));
+    s.lights.push_back(Hittable::new_sphere(V3(0.0, 1.0, 5.0), 0.5, Material::dielectric(1.5)));
+  }
+  s.cam = {V3(0.0, 5.0, 20.0), V3(0.0, 1.5, 0.0), V3(0.0, 1.0, 0.0), 35.0, 0.1, 20.0, 0.0, 1.0};
+  s.background = V3(0.05, 0.07, 0.1);
+  s.rotate_bbox = (seed & 1) ? RotateBBox::Correct : RotateBBox::Reference;
+}
+
 // main.rs:117-124 plus the three extra ids
 inline SceneDef build_scene_def(const SceneSpec& spec) {
   SceneDef s;
@@ -309,6 +384,7 @@ inline SceneDef build_scene_def(const SceneSpec& spec) {
     case 6: cornell_box(s); break;
     case 7: bvh_stress(s, spec.scene_seed, spec.n); break;
     case 8: final_scene(s, spec); break;
+    case 9: mixed_scene(s, spec.scene_seed, spec.n); break;
     default: small_scene(s); break;
   }
   return s;

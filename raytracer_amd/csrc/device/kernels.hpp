@@ -299,6 +299,12 @@ template <typename R> RT_DEV RayT<R> camera_ray(const CameraView<R>& cam, R s, R
   return r;
 }
 
+// The path wants to go on but the depth budget is spent: the reference still multiplies the zero that
+// ray_color(depth 0) returns (main.rs:73-75) into `attenuation * scattering_pdf * ... / pdf_value`
+// (main.rs:93-97), so a vertex whose pdf_value is 0 or NaN (Q9: a scatter point on or inside a light sphere)
+// turns the sample into NaN even here.  thr already holds that product's factor: add thr * 0.
+template <typename R> RT_DEV void depth_exhausted(Vec3<R>& L, Vec3<R> thr) { L = L + thr * Vec3<R>(0, 0, 0); }
+
 RT_DEV uint32_t wave_sum(uint32_t v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -477,7 +483,10 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : RT_RE
       RT_STAMP(5);
       ++slot;
       --depth_left;
-      if (depth_left == 0) cont = false;  // the next ray_color call would return 0
+      if (depth_left == 0 && cont) {  // the next ray_color call would return 0
+        depth_exhausted(L, thr);
+        cont = false;
+      }
       if (EARLY_EXIT && cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
       if (!cont) {
         const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
@@ -638,7 +647,10 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
       }
       ++slot;
       --depth_left;
-      if (depth_left == 0) cont = false;
+      if (depth_left == 0 && cont) {  // the next ray_color call would return 0
+        depth_exhausted(L, thr);
+        cont = false;
+      }
       if (cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
       if (!cont) {
         const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
@@ -839,7 +851,10 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
     RT_STAMP(6);  // shade (or miss)
     ++slot;
     --depth_left;
-    if (depth_left == 0) cont = false;  // the next ray_color call would return 0
+    if (depth_left == 0 && cont) {  // the next ray_color call would return 0
+      depth_exhausted(L, thr);
+      cont = false;
+    }
     if (cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
     if (!cont) {
       const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
@@ -1102,7 +1117,10 @@ __global__ void __launch_bounds__(BLOCK, RT_SORTED_MIN_WAVES) render_sorted_kern
       rd = ray.d;
       ++slot;
       --depth_left;
-      if (depth_left == 0) cont = false;  // the next ray_color call would return 0
+      if (depth_left == 0 && cont) {  // the next ray_color call would return 0
+        depth_exhausted(L, thr);
+        cont = false;
+      }
       if (cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
       if (!cont) finish();
     }

@@ -207,6 +207,80 @@ SceneDef final_scene(const SceneOpts& o) {
   return s;
 }
 
+// Scene 9: the parity tests' generator of feature combinations (not a reference scene, not a benchmark config).
+// Draw list per object: shape class, material class, x, y, z, size, angle (degrees), axis, three colour
+// components, fuzz — the oracle builds the same scene from the same list with its own code.
+SceneDef mixed_scene(uint64_t seed, uint32_t n) {
+  SceneDef s;
+  Stream r = scene_stream(seed, 0);
+  const Color pale(0.9, 0.9, 0.9);
+  s.world.push_back(Hittable::new_cube(Point(-40.0, -1.1, -40.0), Point(40.0, -0.1, 40.0),
+                                       Material::new_lambertian_with_texture(Texture::new_checker_color(Color(0.2, 0.3, 0.1), pale))));
+  for (uint32_t i = 0; i < n; ++i) {
+    const int shape_class = (int)(r.next_f64() * 9.0);
+    const int material_class = (int)(r.next_f64() * 7.0);
+    const double px = r.range(-9.0, 9.0), py = r.range(0.4, 3.5), pz = r.range(-9.0, 9.0);
+    const double size = r.range(0.25, 0.9);
+    const double degrees = r.range(-60.0, 60.0);
+    const int axis_index = (int)(r.next_f64() * 3.0);
+    const double c1 = r.next_f64(), c2 = r.next_f64(), c3 = r.next_f64();
+    const double fuzz = r.range(0.0, 0.5);
+    Vector axis(0.0, 0.0, 0.0);
+    axis[axis_index] = 1.0;
+    const Point centre(px, py, pz), origin(0.0, 0.0, 0.0);
+    const Point lo(-size, -size, -size), hi(size, size, size);
+    const Color tint(c1, c2, c3);
+    Material surface;
+    if (material_class == 0) surface = Material::new_lambertian(tint);
+    else if (material_class == 1) surface = Material::new_lambertian_with_texture(Texture::new_checker_color(tint, pale));
+    else if (material_class == 2) surface = Material::new_lambertian_with_texture(Texture::new_normal());
+    else if (material_class == 3) surface = Material::new_lambertian_with_texture(Texture::new_uv());
+    else if (material_class == 4) surface = Material::new_metal(Color(0.5 + 0.5 * c1, 0.5 + 0.5 * c2, 0.5 + 0.5 * c3), fuzz);
+    else if (material_class == 5) surface = Material::new_dielectric(1.5);
+    else surface = Material::new_isotropic(tint);
+    const double density = 0.5 + 2.0 * c2;
+    const double turn = to_radians(degrees);
+    Hittable h;
+    if (shape_class == 0) {
+      h = Hittable::new_sphere(centre, size, surface);
+    } else if (shape_class == 1) {
+      h = Hittable::new_moving_sphere(centre, add(centre, Vector(0.0, 0.5 * c1, 0.0)), 0.0, 1.0, size, surface);
+    } else if (shape_class == 2) {
+      h = Hittable::new_cube(add(centre, lo), add(centre, hi), surface);
+    } else if (shape_class == 3) {
+      h = Hittable::new_rotate(Hittable::new_cube(add(centre, lo), add(centre, hi), surface), turn, axis);
+    } else if (shape_class == 4) {
+      h = Hittable::new_translate(Hittable::new_rotate(Hittable::new_cube(lo, hi, surface), turn, axis), centre);
+    } else if (shape_class == 5) {
+      h = Hittable::new_translate(Hittable::new_rotate(Hittable::new_sphere(origin, size, surface), turn, axis), centre);
+    } else if (shape_class == 6) {
+      h = Hittable::new_constant_medium(Hittable::new_sphere(centre, 1.5 * size, surface), density, tint);
+    } else if (shape_class == 7) {
+      h = Hittable::new_constant_medium(
+          Hittable::new_translate(Hittable::new_rotate(Hittable::new_cube(lo, hi, surface), turn, axis), centre), density, tint);
+    } else {
+      h = Hittable::new_translate(Hittable::new_constant_medium(Hittable::new_sphere(origin, 1.5 * size, surface), density, tint),
+                                  centre);
+    }
+    s.world.push_back(h);
+  }
+  const Hittable lamp_a = Hittable::new_sphere(Point(-3.0, 7.0, 2.0), 1.0, Material::new_diffuse_light(Color(6.0, 6.0, 6.0)));
+  const Hittable lamp_b = Hittable::new_sphere(Point(4.0, 6.0, -3.0), 0.7, Material::new_diffuse_light(Color(9.0, 8.0, 7.0)));
+  s.world.push_back(lamp_a);
+  s.world.push_back(lamp_b);
+  s.lights.push_back(lamp_a);
+  if (seed % 4 != 1) s.lights.push_back(lamp_b);
+  if (seed % 3 == 0) {  // a non-emitting entry in the lights list, as simple_light has (scenes.rs:139-143)
+    const Hittable bead = Hittable::new_sphere(Point(0.0, 1.0, 5.0), 0.5, Material::new_dielectric(1.5));
+    s.world.push_back(bead);
+    s.lights.push_back(bead);
+  }
+  s.cam = CameraSpec{Point(0.0, 5.0, 20.0), Point(0.0, 1.5, 0.0), Vector(0.0, 1.0, 0.0), 35.0, 0.1, 20.0, 0.0, 1.0};
+  s.background = Color(0.05, 0.07, 0.1);
+  s.rotate_bbox = (seed & 1) ? RotateBBox::Correct : RotateBBox::Reference;
+  return s;
+}
+
 SceneDef scene_by_id(const SceneOpts& o) {
   switch (o.scene_id) {
     case 0: return random_scene(o.scene_seed);
@@ -217,6 +291,7 @@ SceneDef scene_by_id(const SceneOpts& o) {
     case 6: return cornell_box();
     case 7: return bvh_stress(o.scene_seed, o.n);
     case 8: return final_scene(o);
+    case 9: return mixed_scene(o.scene_seed, o.n);
     default: return small_scene();  // main.rs:123
   }
 }

@@ -1,0 +1,92 @@
+"""Parity on GENERATED scenes (scene id 9, `mixed_scene`): every primitive kind under every wrapper nesting
+the flattener accepts — Rotate(Cube), Translate(Rotate(Cube | Sphere)), ConstantMedium over a bare, a wrapped
+and (wrapped from outside) a translated boundary — with every material and texture kind, one, two or three
+entries in `lights` (one of them non-emitting), and both Rotate::bounding_box modes (Q3).  The host layer
+and the oracle each build the scene with their own code from the same draw list, so this exercises feature
+COMBINATIONS none of the reference's six scenes contains.  Small n takes the leaf-list path where the scene
+is eligible, large n the BVH walks."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from test_host_bvh import _compare
+
+W, ASPECT = 64, 1.5
+CASES = [(seed, n) for seed in (1, 2, 3, 4, 5, 6) for n in (9, 70)]
+
+
+def _scenes(seed, n, device=True):
+    import raytracer_amd as R
+    hs = R.HostScene(9, ASPECT, n=n, scene_seed=seed)
+    os_ = O.OracleScene(9, ASPECT, n=n, scene_seed=seed)
+    ds = R.DeviceScene(hs, 0) if device else None
+    return hs, ds, os_, R.image_height(W, ASPECT)
+
+
+@pytest.mark.parametrize("seed,n", CASES + [(7, 400), (8, 1)])
+def test_mixed_scene_tree_and_camera_equal_the_oracles(seed, n):
+    hs, _, os_, _ = _scenes(seed, n, device=False)
+    _compare(hs, os_)
+    assert hs.n_objects == n + 3 + (1 if seed % 3 == 0 else 0)
+    assert hs.desc.n_lights == 1 + (1 if seed % 4 != 1 else 0) + (1 if seed % 3 == 0 else 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n", CASES)
+def test_mixed_primary_hits(seed, n):
+    hs, ds, os_, h = _scenes(seed, n)
+    for time in (0.0, 0.7):
+        oid, ot, on, ouv, off = os_.primary_hits(W, h, seed=3, time=time)
+        gid, gt, gn, guv, gff = ds.primary_hits(W, h, seed=3, time=time, f64=True)
+        assert np.array_equal(gid, oid), f"{(gid != oid).sum()} primary ids differ"
+        hit = oid != 0xFFFFFFFF
+        assert np.array_equal(gff[hit], off[hit])
+        np.testing.assert_allclose(gt[hit], ot[hit], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(gn[hit], on[hit], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(guv[hit], ouv[hit], rtol=0, atol=1e-12)
+        # f32 production kernels: silhouettes may move by a fraction of a pixel
+        fid, ft, fn, _, _ = ds.primary_hits(W, h, seed=3, time=time, f64=False)
+        same = fid == oid
+        assert (~same).mean() <= 0.005
+        ok = same & hit
+        rel = np.abs(ft[ok] - ot[ok]) / np.abs(ot[ok])
+        assert np.quantile(rel, 0.995) <= 1e-5 and rel.max() <= 1e-3
+        # and the production walk (leaf list / ordered walk) picks exactly the reference-order walk's winner
+        a = ds.primary_hits(W, h, seed=3, time=time, fast=True)
+        assert np.array_equal(a[0], fid) and np.array_equal(a[1][fid != 0xFFFFFFFF], ft[fid != 0xFFFFFFFF])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n", CASES)
+def test_mixed_render_f64_follows_oracle_path_for_path(seed, n):
+    hs, ds, os_, h = _scenes(seed, n)
+    spp, depth = 8, 12
+    g, gst = ds.render(W, h, spp, depth, seed=11, sample_offset=5, stats=True, f64=True)
+    o, ocnt, _ = os_.render(W, h, spp, depth, seed=11, sample_offset=5)
+    fin = np.isfinite(o) & np.isfinite(g)
+    assert (np.isfinite(o) == np.isfinite(g)).mean() >= 0.999
+    err = np.abs(g - o)[fin] / (1.0 + np.abs(o[fin]))
+    assert np.quantile(err, 0.999) <= 1e-9, f"err q99.9 {np.quantile(err, 0.999)}"
+    assert (err > 1e-9).mean() <= 1e-3
+    for k in ("rays", "nodes_visited", "sphere_tests", "cube_tests", "closest_hits", "diffuse_vertices",
+              "specular_vertices", "emitter_hits", "misses", "light_probes", "medium_probes"):
+        assert abs(gst[k] - ocnt[k]) <= max(2, 1e-4 * ocnt[k]), (k, gst[k], ocnt[k])  # one path may flip on an ulp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n", CASES)
+def test_mixed_f32_tracks_f64_and_both_f32_walks_agree(seed, n):
+    hs, ds, os_, h = _scenes(seed, n)
+    for d in (2, 4):
+        a, sa = ds.render(W, h, 64, d, seed=21, stats=True)
+        b, sb = ds.render(W, h, 64, d, seed=21, stats=True, f64=True)
+        c, sc = ds.render(W, h, 64, d, seed=21, stats=True, force_bvh=True)
+        # seeds divisible by 3 put a glass bead into `lights`: a scatter point on or inside it has pdf_value
+        # NaN (Q9), which poisons the whole pixel in f64 (as in the reference) and drops one sample in f32 —
+        # compare the pixels that are finite in all three
+        fin = np.isfinite(a).all(axis=-1) & np.isfinite(b).all(axis=-1) & np.isfinite(c).all(axis=-1)
+        ta, tb, tc = (float(np.clip(x[fin], 0, 64 * 4).sum()) for x in (a, b, c))
+        assert abs(ta / tb - 1.0) <= 0.01, (d, ta, tb)
+        assert abs(ta / tc - 1.0) <= 0.005, (d, ta, tc)
+        same = np.isclose(a, c, rtol=1e-4, atol=1e-5, equal_nan=True).all(axis=-1)
+        assert same.mean() >= 0.93, same.mean()
