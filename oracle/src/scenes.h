@@ -297,18 +297,21 @@ inline void final_scene(SceneDef& s, const SceneSpec& spec) {
 
 // Scene 9, "mixed_scene": not a reference scene and not a benchmark config — a seeded generator of feature
 // COMBINATIONS for the parity tests (every primitive kind under every wrapper nesting the flattener accepts,
-// every material and texture kind, one or several lights incl. a non-emitting one, both Rotate-bbox modes).
+// every material and texture kind (the image texture when texels are given), a negative-radius sphere, one or
+// several lights incl. a non-emitting one, both Rotate-bbox modes).
 // The host layer has its own copy (rth_scenes.cpp) written against the same draw list:
 //   per object, in order: shape class, material class, x, y, z, size, angle, axis, a1, a2, a3, fuzz.
-inline void mixed_scene(SceneDef& s, uint64_t seed, uint32_t n) {
+inline void mixed_scene(SceneDef& s, const SceneSpec& spec) {
+  const uint64_t seed = spec.scene_seed;
+  const uint32_t n = spec.n;
   Rng rng = scene_rng(seed, 0);
   // the ground's top face is NOT at y = 0: a checker (sin(10 y)) on a plane at a zero of the sine picks its
   // colour from the rounding noise of p.y, differently in every arithmetic
   s.world.push_back(Hittable::new_cube(V3(-40.0, -1.1, -40.0), V3(40.0, -0.1, 40.0),
                                        Material::lambertian_tex(Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9)))));
   for (uint32_t i = 0; i < n; ++i) {
-    const int shape = (int)(rng.next_f64() * 9.0);
-    const int mat = (int)(rng.next_f64() * 7.0);
+    const int shape = (int)(rng.next_f64() * 14.0);
+    const int mat = (int)(rng.next_f64() * 8.0);
     const double x = rng.range(-9.0, 9.0);
     const double y = rng.range(0.4, 3.5);
     const double z = rng.range(-9.0, 9.0);
@@ -320,6 +323,7 @@ inline void mixed_scene(SceneDef& s, uint64_t seed, uint32_t n) {
     const double a3 = rng.next_f64();
     const double fuzz = rng.range(0.0, 0.5);
     const V3 axis(axis_k == 0 ? 1.0 : 0.0, axis_k == 1 ? 1.0 : 0.0, axis_k == 2 ? 1.0 : 0.0);
+    const V3 axis2(axis_k == 2 ? 1.0 : 0.0, axis_k == 0 ? 1.0 : 0.0, axis_k == 1 ? 1.0 : 0.0);  // the next axis
     const V3 c(x, y, z), col(a1, a2, a3), half(sz, sz, sz);
     Material m;
     switch (mat) {
@@ -329,7 +333,8 @@ inline void mixed_scene(SceneDef& s, uint64_t seed, uint32_t n) {
       case 3: m = Material::lambertian_tex(Texture::uv()); break;
       case 4: m = Material::metal(V3(0.5 + 0.5 * a1, 0.5 + 0.5 * a2, 0.5 + 0.5 * a3), fuzz); break;
       case 5: m = Material::dielectric(1.5); break;
-      default: m = Material::isotropic(col); break;
+      case 6: m = Material::isotropic(col); break;
+      default: m = Material::lambertian_tex(spec.texels ? earth_texture(spec) : Texture::uv()); break;
     }
     const double density = 0.5 + 2.0 * a2;
     const V3 zero(0.0, 0.0, 0.0);
@@ -349,9 +354,23 @@ inline void mixed_scene(SceneDef& s, uint64_t seed, uint32_t n) {
         s.world.push_back(Hittable::new_constant_medium(
             Hittable::new_translate(Hittable::new_rotate(Hittable::new_cube(zero - half, half, m), angle, axis), c), density, col));
         break;
-      default:
+      case 8:
         s.world.push_back(
             Hittable::new_translate(Hittable::new_constant_medium(Hittable::new_sphere(zero, 1.5 * sz, m), density, col), c));
+        break;
+      case 9: s.world.push_back(Hittable::new_sphere(c, -sz, m)); break;  // negative radius: normals point inward (Q15)
+      case 10: s.world.push_back(Hittable::new_rotate(Hittable::new_translate(Hittable::new_cube(zero - half, half, m), c), angle * 0.1, axis)); break;
+      case 11:
+        s.world.push_back(Hittable::new_translate(
+            Hittable::new_rotate(Hittable::new_rotate(Hittable::new_cube(zero - half, half, m), angle, axis), 0.5 * angle, axis2), c));
+        break;
+      case 12:
+        s.world.push_back(Hittable::new_constant_medium(
+            Hittable::new_moving_sphere(c, c + V3(0.3 * a3, 0.0, 0.0), 0.0, 1.0, 1.5 * sz, m), density, col));
+        break;
+      default:
+        s.world.push_back(Hittable::new_translate(
+            Hittable::new_rotate(Hittable::new_constant_medium(Hittable::new_cube(zero - half, half, m), density, col), angle, axis), c));
         break;
     }
   }
@@ -384,7 +403,7 @@ inline SceneDef build_scene_def(const SceneSpec& spec) {
     case 6: cornell_box(s); break;
     case 7: bvh_stress(s, spec.scene_seed, spec.n); break;
     case 8: final_scene(s, spec); break;
-    case 9: mixed_scene(s, spec.scene_seed, spec.n); break;
+    case 9: mixed_scene(s, spec); break;
     default: small_scene(s); break;
   }
   return s;

@@ -87,10 +87,11 @@ RT_DEV bool sphere_t<float>(Vec3<float> o, Vec3<float> d, float a, Vec3<float> c
                             float t_max, float& t_out) {
   const double ocx = (double)o.x - (double)c.x, ocy = (double)o.y - (double)c.y, ocz = (double)o.z - (double)c.z;
   const double dx = d.x, dy = d.y, dz = d.z;
-  const double half_b = ocx * dx + ocy * dy + ocz * dz;
-  const double cc = ocx * ocx + ocy * ocy + ocz * ocz - (double)radius * (double)radius;
-  const double a64 = dx * dx + dy * dy + dz * dz;
-  const double disc = half_b * half_b - a64 * cc;
+  // explicit FMAs: one fixed form at every inlined copy (see mul_add3)
+  const double half_b = __builtin_fma(ocz, dz, __builtin_fma(ocy, dy, ocx * dx));
+  const double cc = __builtin_fma(ocz, ocz, __builtin_fma(ocy, ocy, ocx * ocx)) - (double)radius * (double)radius;
+  const double a64 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+  const double disc = __builtin_fma(half_b, half_b, -(a64 * cc));
   if (disc < 0.0) return false;
   const double sqrtd = (double)rroot((float)disc);
   const float inv_a = rrcp(a);
@@ -120,8 +121,20 @@ RT_DEV Vec3<float> sphere_outward<float>(Vec3<float> o, Vec3<float> d, float t, 
 // hittable.rs:66-72
 template <typename R> RT_DEV Vec3<R> moving_center(const MSphere<R>& m, R time) {
   Vec3<R> c0(m.c0[0], m.c0[1], m.c0[2]), c1(m.c1[0], m.c1[1], m.c1[2]);
-  return c0 + rdiv(time - m.t0, m.t1 - m.t0) * (c1 - c0);
+  const R s = rdiv(time - m.t0, m.t1 - m.t0);
+  if constexpr (sizeof(R) == 4)  // one fixed fused form (see mul_add3)
+    return {__builtin_fmaf(s, c1.x - c0.x, c0.x), __builtin_fmaf(s, c1.y - c0.y, c0.y), __builtin_fmaf(s, c1.z - c0.z, c0.z)};
+  else
+    return c0 + s * (c1 - c0);
 }
+
+// t1 + hit_distance / ray_length (hittable.rs:346-348).  The f32 kernels evaluate it in three places (leaf list,
+// reference-order walk, ordered walk); under -ffp-contract=fast the compiler may fuse the multiply-add in one
+// and not in another, and the walks would then disagree in the last bit of t.  One explicit FMA for all of them.
+RT_DEV float medium_exit_t(float t1, float hit_distance, float ray_length) {
+  return __builtin_fmaf(hit_distance, __builtin_amdgcn_rcpf(ray_length), t1);
+}
+RT_DEV double medium_exit_t(double t1, double hit_distance, double ray_length) { return t1 + hit_distance / ray_length; }
 
 // One simple primitive (SPHERE / MSPHERE / CUBE) against a ray in that primitive's frame.
 template <typename R, bool STATS>
@@ -154,16 +167,16 @@ RT_DEV bool prim_t(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, Vec3<
 template <typename R> RT_DEV Vec3<R> inverse3(Vec3<R> d) { return {rrcp(d.x), rrcp(d.y), rrcp(d.z)}; }
 
 template <typename R> RT_DEV Vec3<R> xf_dir(const R* m, Vec3<R> v) {
-  return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z,
-          m[6] * v.x + m[7] * v.y + m[8] * v.z};
+  return {mul_add3(m[0], v.x, m[1], v.y, m[2], v.z), mul_add3(m[3], v.x, m[4], v.y, m[5], v.z),
+          mul_add3(m[6], v.x, m[7], v.y, m[8], v.z)};
 }
 template <typename R> RT_DEV Vec3<R> xf_point(const R* m, const R* b, Vec3<R> v) {
-  return {m[0] * v.x + m[1] * v.y + m[2] * v.z + b[0], m[3] * v.x + m[4] * v.y + m[5] * v.z + b[1],
-          m[6] * v.x + m[7] * v.y + m[8] * v.z + b[2]};
+  return {mul_add3(m[0], v.x, m[1], v.y, m[2], v.z) + b[0], mul_add3(m[3], v.x, m[4], v.y, m[5], v.z) + b[1],
+          mul_add3(m[6], v.x, m[7], v.y, m[8], v.z) + b[2]};
 }
 template <typename R> RT_DEV Vec3<R> xf_dir_transposed(const R* m, Vec3<R> v) {
-  return {m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z,
-          m[2] * v.x + m[5] * v.y + m[8] * v.z};
+  return {mul_add3(m[0], v.x, m[3], v.y, m[6], v.z), mul_add3(m[1], v.x, m[4], v.y, m[7], v.z),
+          mul_add3(m[2], v.x, m[5], v.y, m[8], v.z)};
 }
 
 // hittable.rs:331: the medium's second boundary probe starts at hit1.t + 0.0001.  In f32 that sum
@@ -233,7 +246,7 @@ RT_DEV bool complex_t(const SceneView<R>& sc, uint32_t idx, const RayT<R>& r, R 
   R distance_inside_boundary = (t2 - t1) * ray_length;
   R hit_distance = neg_inv_density * rlog(rng.template keyed<R>(cx.object));
   if (hit_distance > distance_inside_boundary) return false;
-  t_out = t1 + rdiv(hit_distance, ray_length);
+  t_out = medium_exit_t(t1, hit_distance, ray_length);
   return true;
 }
 
@@ -328,7 +341,7 @@ RT_DEV bool leaf_t_unified(const SceneView<float>& sc, uint32_t ref, const RayT<
   const float ray_length = length(r.d);  // rigid maps keep |d|
   const float hit_distance = neg_inv_density * rlog(rng.template keyed<float>(object));
   if (hit_distance > (t2 - t1) * ray_length) return false;
-  t_out = t1 + rdiv(hit_distance, ray_length);
+  t_out = medium_exit_t(t1, hit_distance, ray_length);
   return true;
 }
 
@@ -567,7 +580,7 @@ RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, const RayT<floa
       const float ray_length = length(r.d);  // rigid maps keep |d|
       const float hit_distance = rec[LIN_NID] * rlog(rng.keyed<float>(__float_as_uint(rec[LIN_OBJECT])));
       if (hit_distance > (t2 - t1) * ray_length) return false;
-      t = t1 + rdiv(hit_distance, ray_length);
+      t = medium_exit_t(t1, hit_distance, ray_length);
       return true;
     };
     if (flags & LINF_XF) {  // wave-uniform branch

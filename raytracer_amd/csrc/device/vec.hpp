@@ -86,7 +86,17 @@ template <typename R> RT_DEV Vec3<R> operator/(Vec3<R> a, R s) {
     return {a.x / s, a.y / s, a.z / s};
   }
 }
-template <typename R> RT_DEV R dot(Vec3<R> a, Vec3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// a0 b0 + a1 b1 + a2 b2.  f32: ONE fixed fused form.  Under -ffp-contract=fast the compiler decides per inlined
+// copy whether and how to fuse `x*y + z*w + ...`; two walks that reach the same leaf through different code
+// (leaf list, reference-order walk, ordered walk) would then disagree in the last bit of a dot product and,
+// now and then, of t.  f64 (the audit kernels, -ffp-contract=off) keeps the oracle's plain expression.
+template <typename R> RT_DEV R mul_add3(R a0, R b0, R a1, R b1, R a2, R b2) {
+  if constexpr (sizeof(R) == 4)
+    return __builtin_fmaf(a2, b2, __builtin_fmaf(a1, b1, a0 * b0));
+  else
+    return a0 * b0 + a1 * b1 + a2 * b2;
+}
+template <typename R> RT_DEV R dot(Vec3<R> a, Vec3<R> b) { return mul_add3(a.x, b.x, a.y, b.y, a.z, b.z); }
 template <typename R> RT_DEV Vec3<R> cross(Vec3<R> a, Vec3<R> b) {
   return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }

@@ -210,15 +210,17 @@ SceneDef final_scene(const SceneOpts& o) {
 // Scene 9: the parity tests' generator of feature combinations (not a reference scene, not a benchmark config).
 // Draw list per object: shape class, material class, x, y, z, size, angle (degrees), axis, three colour
 // components, fuzz — the oracle builds the same scene from the same list with its own code.
-SceneDef mixed_scene(uint64_t seed, uint32_t n) {
+SceneDef mixed_scene(const SceneOpts& o) {
   SceneDef s;
+  const uint64_t seed = o.scene_seed;
+  const uint32_t n = o.n;
   Stream r = scene_stream(seed, 0);
   const Color pale(0.9, 0.9, 0.9);
   s.world.push_back(Hittable::new_cube(Point(-40.0, -1.1, -40.0), Point(40.0, -0.1, 40.0),
                                        Material::new_lambertian_with_texture(Texture::new_checker_color(Color(0.2, 0.3, 0.1), pale))));
   for (uint32_t i = 0; i < n; ++i) {
-    const int shape_class = (int)(r.next_f64() * 9.0);
-    const int material_class = (int)(r.next_f64() * 7.0);
+    const int shape_class = (int)(r.next_f64() * 14.0);
+    const int material_class = (int)(r.next_f64() * 8.0);
     const double px = r.range(-9.0, 9.0), py = r.range(0.4, 3.5), pz = r.range(-9.0, 9.0);
     const double size = r.range(0.25, 0.9);
     const double degrees = r.range(-60.0, 60.0);
@@ -237,7 +239,8 @@ SceneDef mixed_scene(uint64_t seed, uint32_t n) {
     else if (material_class == 3) surface = Material::new_lambertian_with_texture(Texture::new_uv());
     else if (material_class == 4) surface = Material::new_metal(Color(0.5 + 0.5 * c1, 0.5 + 0.5 * c2, 0.5 + 0.5 * c3), fuzz);
     else if (material_class == 5) surface = Material::new_dielectric(1.5);
-    else surface = Material::new_isotropic(tint);
+    else if (material_class == 6) surface = Material::new_isotropic(tint);
+    else surface = Material::new_lambertian_with_texture(o.texels ? earthmap(o) : Texture::new_uv());
     const double density = 0.5 + 2.0 * c2;
     const double turn = to_radians(degrees);
     Hittable h;
@@ -258,9 +261,24 @@ SceneDef mixed_scene(uint64_t seed, uint32_t n) {
     } else if (shape_class == 7) {
       h = Hittable::new_constant_medium(
           Hittable::new_translate(Hittable::new_rotate(Hittable::new_cube(lo, hi, surface), turn, axis), centre), density, tint);
-    } else {
+    } else if (shape_class == 8) {
       h = Hittable::new_translate(Hittable::new_constant_medium(Hittable::new_sphere(origin, 1.5 * size, surface), density, tint),
                                   centre);
+    } else if (shape_class == 9) {
+      h = Hittable::new_sphere(centre, -size, surface);  // Q15: a negative radius flips the normal
+    } else if (shape_class == 10) {
+      h = Hittable::new_rotate(Hittable::new_translate(Hittable::new_cube(lo, hi, surface), centre), turn * 0.1, axis);
+    } else if (shape_class == 11) {
+      Vector next_axis(0.0, 0.0, 0.0);
+      next_axis[(axis_index + 1) % 3] = 1.0;
+      h = Hittable::new_translate(
+          Hittable::new_rotate(Hittable::new_rotate(Hittable::new_cube(lo, hi, surface), turn, axis), 0.5 * turn, next_axis), centre);
+    } else if (shape_class == 12) {
+      h = Hittable::new_constant_medium(
+          Hittable::new_moving_sphere(centre, add(centre, Vector(0.3 * c3, 0.0, 0.0)), 0.0, 1.0, 1.5 * size, surface), density, tint);
+    } else {
+      h = Hittable::new_translate(
+          Hittable::new_rotate(Hittable::new_constant_medium(Hittable::new_cube(lo, hi, surface), density, tint), turn, axis), centre);
     }
     s.world.push_back(h);
   }
@@ -291,7 +309,7 @@ SceneDef scene_by_id(const SceneOpts& o) {
     case 6: return cornell_box();
     case 7: return bvh_stress(o.scene_seed, o.n);
     case 8: return final_scene(o);
-    case 9: return mixed_scene(o.scene_seed, o.n);
+    case 9: return mixed_scene(o);
     default: return small_scene();  // main.rs:123
   }
 }

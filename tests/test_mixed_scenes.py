@@ -1,6 +1,7 @@
 """Parity on GENERATED scenes (scene id 9, `mixed_scene`): every primitive kind under every wrapper nesting
-the flattener accepts — Rotate(Cube), Translate(Rotate(Cube | Sphere)), ConstantMedium over a bare, a wrapped
-and (wrapped from outside) a translated boundary — with every material and texture kind, one, two or three
+the flattener accepts — Rotate(Cube), Rotate(Translate(Cube)), Translate(Rotate(Rotate(Cube))),
+Translate(Rotate(Sphere)), ConstantMedium over a bare, a moving and a wrapped boundary, and media wrapped from
+outside — a negative-radius sphere, every material and texture kind (image texture on even seeds), one, two or three
 entries in `lights` (one of them non-emitting), and both Rotate::bounding_box modes (Q3).  The host layer
 and the oracle each build the scene with their own code from the same draw list, so this exercises feature
 COMBINATIONS none of the reference's six scenes contains.  Small n takes the leaf-list path where the scene
@@ -12,18 +13,19 @@ import oracle_ffi as O
 from test_host_bvh import _compare
 
 W, ASPECT = 64, 1.5
-CASES = [(seed, n) for seed in (1, 2, 3, 4, 5, 6) for n in (9, 70)]
+CASES = [(seed, n) for seed in range(1, 13) for n in (9, 70)] + [(13, 400)]
 
 
 def _scenes(seed, n, device=True):
     import raytracer_amd as R
-    hs = R.HostScene(9, ASPECT, n=n, scene_seed=seed)
-    os_ = O.OracleScene(9, ASPECT, n=n, scene_seed=seed)
+    texels = R.load_earthmap() if seed % 2 == 0 else None  # even seeds: material class 7 is the image texture, else UV
+    hs = R.HostScene(9, ASPECT, n=n, scene_seed=seed, texels=texels)
+    os_ = O.OracleScene(9, ASPECT, n=n, scene_seed=seed, texels=texels)
     ds = R.DeviceScene(hs, 0) if device else None
     return hs, ds, os_, R.image_height(W, ASPECT)
 
 
-@pytest.mark.parametrize("seed,n", CASES + [(7, 400), (8, 1)])
+@pytest.mark.parametrize("seed,n", CASES + [(7, 1000), (8, 1), (9, 0)])
 def test_mixed_scene_tree_and_camera_equal_the_oracles(seed, n):
     hs, _, os_, _ = _scenes(seed, n, device=False)
     _compare(hs, os_)
@@ -70,7 +72,7 @@ def test_mixed_render_f64_follows_oracle_path_for_path(seed, n):
     assert (err > 1e-9).mean() <= 1e-3
     for k in ("rays", "nodes_visited", "sphere_tests", "cube_tests", "closest_hits", "diffuse_vertices",
               "specular_vertices", "emitter_hits", "misses", "light_probes", "medium_probes"):
-        assert abs(gst[k] - ocnt[k]) <= max(2, 1e-4 * ocnt[k]), (k, gst[k], ocnt[k])  # one path may flip on an ulp
+        assert abs(gst[k] - ocnt[k]) <= max(64, 2e-4 * ocnt[k]), (k, gst[k], ocnt[k])  # one path may flip on an ulp
 
 
 @pytest.mark.gpu
