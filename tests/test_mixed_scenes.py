@@ -89,6 +89,6 @@ def test_mixed_f32_tracks_f64_and_both_f32_walks_agree(seed, n):
         fin = np.isfinite(a).all(axis=-1) & np.isfinite(b).all(axis=-1) & np.isfinite(c).all(axis=-1)
         ta, tb, tc = (float(np.clip(x[fin], 0, 64 * 4).sum()) for x in (a, b, c))
         assert abs(ta / tb - 1.0) <= 0.01, (d, ta, tb)
-        assert abs(ta / tc - 1.0) <= 0.005, (d, ta, tc)
+        assert abs(ta / tc - 1.0) <= 1e-4, (d, ta, tc)
         same = np.isclose(a, c, rtol=1e-4, atol=1e-5, equal_nan=True).all(axis=-1)
-        assert same.mean() >= 0.93, same.mean()
+        assert same.mean() >= 0.999, same.mean()
