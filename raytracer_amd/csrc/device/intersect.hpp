@@ -82,9 +82,13 @@ RT_DEV bool sphere_t(Vec3<R> o, Vec3<R> d, R a, Vec3<R> c, R radius, R t_min, R 
 // (scenes.rs:59,148) and for small far spheres, which would break the 1e-5 bound on t and
 // normals.  The inputs stay f32; only the cancelling dot products are carried in f64
 // (vector f64 runs at half the f32 rate on gfx950), then everything returns to f32.
-template <>
-RT_DEV bool sphere_t<float>(Vec3<float> o, Vec3<float> d, float a, Vec3<float> c, float radius, float t_min,
-                            float t_max, float& t_out) {
+struct SphereRoots {
+  float near_t, far_t;  // (-half_b -/+ sqrt(disc)) / a
+  bool real;            // disc >= 0 (a NaN discriminant counts as real, as in the reference's `< 0.0` test)
+};
+// Both roots at once: a constant medium probes its boundary twice with different windows
+// (hittable.rs:324-331); the quadratic is solved once and each probe only picks its root.
+RT_DEV SphereRoots sphere_roots(Vec3<float> o, Vec3<float> d, float a, Vec3<float> c, float radius) {
   const double ocx = (double)o.x - (double)c.x, ocy = (double)o.y - (double)c.y, ocz = (double)o.z - (double)c.z;
   const double dx = d.x, dy = d.y, dz = d.z;
   // explicit FMAs: one fixed form at every inlined copy (see mul_add3)
@@ -92,16 +96,29 @@ RT_DEV bool sphere_t<float>(Vec3<float> o, Vec3<float> d, float a, Vec3<float> c
   const double cc = __builtin_fma(ocz, ocz, __builtin_fma(ocy, ocy, ocx * ocx)) - (double)radius * (double)radius;
   const double a64 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
   const double disc = __builtin_fma(half_b, half_b, -(a64 * cc));
-  if (disc < 0.0) return false;
+  SphereRoots s;
+  s.real = !(disc < 0.0);
   const double sqrtd = (double)rroot((float)disc);
   const float inv_a = rrcp(a);
-  float root = (float)(-half_b - sqrtd) * inv_a;
+  s.near_t = (float)(-half_b - sqrtd) * inv_a;
+  s.far_t = (float)(-half_b + sqrtd) * inv_a;
+  return s;
+}
+// hittable.rs:266-273: the nearest root inside [t_min, t_max]
+RT_DEV bool sphere_pick(const SphereRoots& s, float t_min, float t_max, float& t_out) {
+  if (!s.real) return false;
+  float root = s.near_t;
   if (root < t_min || root > t_max) {
-    root = (float)(-half_b + sqrtd) * inv_a;
+    root = s.far_t;
     if (root < t_min || root > t_max) return false;
   }
   t_out = root;
   return true;
+}
+template <>
+RT_DEV bool sphere_t<float>(Vec3<float> o, Vec3<float> d, float a, Vec3<float> c, float radius, float t_min,
+                            float t_max, float& t_out) {
+  return sphere_pick(sphere_roots(o, d, a, c, radius), t_min, t_max, t_out);
 }
 
 // outward normal (p - c) / radius, hittable.rs:278; the f32 form builds p - c as
@@ -294,6 +311,8 @@ RT_DEV bool leaf_t_unified(const SceneView<float>& sc, uint32_t ref, const RayT<
     p0 = moving_center(m, r.time);
     p1 = Vec3<float>(m.radius, 0.0f, 0.0f);
   }
+  SphereRoots roots;
+  if (!is_cube) roots = sphere_roots(o, d, a, p0, p1.x);  // once, for both probes of a medium
   // probe 0: the hit test proper, or a medium's first boundary probe; probe 1: a medium's second
   float lo = medium ? -Consts<float>::inf : t_min, hi = medium ? Consts<float>::inf : t_max;
   float t1 = 0.0f, t2 = 0.0f;
@@ -312,7 +331,7 @@ RT_DEV bool leaf_t_unified(const SceneView<float>& sc, uint32_t ref, const RayT<
         if (h) cnt.template inc<ST_CUBE_HITS>();
       } else {  // hittable.rs:257-276 / 288-307
         cnt.template inc<ST_SPHERE_TESTS>();
-        h = sphere_t(o, d, a, p0, p1.x, lo, hi, t);
+        h = sphere_pick(roots, lo, hi, t);
         if (h) cnt.template inc<ST_SPHERE_HITS>();
       }
       if (probe == 0) {
