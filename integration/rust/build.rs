@@ -7,7 +7,7 @@ fn main() {
     let src = PathBuf::from(env::var("RT_HIP_SRC").unwrap_or_else(|_| "raytracer_amd/csrc".into()));
     let hipcc = env::var("HIPCC").unwrap_or_else(|_| "/opt/rocm/bin/hipcc".into());
     let common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"];
-    for (file, contract) in [("rt_f32.hip", Some("fast")), ("rt_f64.hip", Some("off")), ("rt_api.hip", None)] {
+    for (file, contract) in [("rt_f32.hip", Some("on")), ("rt_f64.hip", Some("off")), ("rt_api.hip", None)] {
         let mut cmd = Command::new(&hipcc);
         cmd.args(common);
         if let Some(c) = contract {

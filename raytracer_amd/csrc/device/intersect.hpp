@@ -132,7 +132,7 @@ RT_DEV Vec3<float> sphere_outward<float>(Vec3<float> o, Vec3<float> d, float t, 
                                          float radius) {
   Vec3<float> oc((float)((double)o.x - (double)c.x), (float)((double)o.y - (double)c.y),
                  (float)((double)o.z - (double)c.z));
-  return (oc + t * d) / radius;
+  return madd(oc, t, d) / radius;
 }
 
 // hittable.rs:66-72
@@ -146,7 +146,7 @@ template <typename R> RT_DEV Vec3<R> moving_center(const MSphere<R>& m, R time) 
 }
 
 // t1 + hit_distance / ray_length (hittable.rs:346-348).  The f32 kernels evaluate it in three places (leaf list,
-// reference-order walk, ordered walk); under -ffp-contract=fast the compiler may fuse the multiply-add in one
+// reference-order walk, ordered walk); under HIP's default -ffp-contract=fast the compiler may fuse the multiply-add in one
 // and not in another, and the walks would then disagree in the last bit of t.  One explicit FMA for all of them.
 RT_DEV float medium_exit_t(float t1, float hit_distance, float ray_length) {
   return __builtin_fmaf(hit_distance, __builtin_amdgcn_rcpf(ray_length), t1);
@@ -653,7 +653,7 @@ template <typename R> RT_DEV Vec3<R> cube_normal(Vec3<R> rel) {
 template <typename R>
 RT_DEV void prim_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, R t, bool force_uv, HitRec<R>& h) {
   uint32_t kind = ref_kind(ref), idx = ref_index(ref);
-  h.p = r.o + t * r.d;  // Ray::at, ray.rs:19-21
+  h.p = madd(r.o, t, r.d);  // Ray::at, ray.rs:19-21
   if (kind == LEAF_CUBE) {  // hittable.rs:229-255
     Cube<R> c = sc.cubes[idx];
     Attr at = sc.cube_attr[idx];
@@ -730,7 +730,7 @@ RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>&
       h.normal = xf_dir_transposed(m, h.normal);
       h.object = cx_object;
     }
-    h.p = r.o + t * r.d;  // rigid maps: the world-space point is o + t d in any frame
+    h.p = madd(r.o, t, r.d);  // rigid maps: the world-space point is o + t d in any frame
     return;
   }
   if (ref_kind(ref) != LEAF_COMPLEX) {
@@ -754,7 +754,7 @@ RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>&
   if (cx.medium_pos == REF_NONE) {
     prim_record(sc, cx.body, lr, t, force_uv, h);
   } else {  // hittable.rs:349-362: arbitrary normal (1,0,0), uv (0,0), in the medium's frame
-    h.p = lr.o + t * lr.d;
+    h.p = madd(lr.o, t, lr.d);
     h.uv.x = R(0);
     h.uv.y = R(0);
     face_normal(lr.d, Vec3<R>(1, 0, 0), h);
@@ -797,7 +797,7 @@ RT_DEV void lin_hit_record(const SceneView<float>& sc, const float* rec, const R
   if (flags & LINF_MEDIUM) {  // hittable.rs:349-362 (the medium op is outermost in this path's records)
     face_normal(r.d, Vec3<float>(1, 0, 0), h);
   } else if (flags & LINF_CUBE) {
-    const Vec3<float> pl = o + t * d;
+    const Vec3<float> pl = madd(o, t, d);
     const Vec3<float> p0(rec[LIN_PRIM], rec[LIN_PRIM + 1], rec[LIN_PRIM + 2]);
     const Vec3<float> inv_ext(rec[LIN_INVEXT], rec[LIN_INVEXT + 1], rec[LIN_INVEXT + 2]);  // 1 / (p1 - p0)
     const Vec3<float> rel = (pl - p0) * inv_ext;
@@ -809,14 +809,14 @@ RT_DEV void lin_hit_record(const SceneView<float>& sc, const float* rec, const R
     }
     face_normal(d, n, h);
   } else {
-    const Vec3<float> pl = o + t * d;
+    const Vec3<float> pl = madd(o, t, d);
     const Vec3<float> c(rec[LIN_PRIM], rec[LIN_PRIM + 1], rec[LIN_PRIM + 2]);
     const Vec3<float> outward = sphere_outward(o, d, t, pl, c, rec[LIN_PRIM + 3]);
     if (mat.flags & MATF_NEEDS_UV) h.uv = get_sphere_uv(outward);
     face_normal(d, outward, h);
   }
   if ((flags & LINF_XF) && !(flags & LINF_MEDIUM)) h.normal = xf_dir_transposed(rec + LIN_M, h.normal);
-  h.p = r.o + t * r.d;
+  h.p = madd(r.o, t, r.d);
   (void)sc;
 }
 

@@ -114,18 +114,32 @@ RT_DEV R light_pdf_one(const Light<R>& l, Vec3<R> origin, Vec3<R> direction, Cnt
 // it at t >= 0" is "the direction lies inside the tangent cone": cos(angle to the centre) >=
 // cos_theta_max — every quantity of which the pdf needs anyway.  An origin inside (or on) the
 // sphere always hits, and the pdf is the same NaN / inf the reference produces (Q9).
+struct LightCone {  // what both Hittable::random and pdf_value need of a sphere light seen from `origin`
+  Vec3<float> to_c;   // centre - origin
+  float d2, r2;       // |to_c|^2, radius^2
+  float cos_theta_max, inv_len;  // sqrt(1 - r^2/d^2) (hittable.rs:487, alias.rs:87), 1/|to_c|
+};
+RT_DEV LightCone light_cone(const Light<float>& l, Vec3<float> origin) {
+  LightCone c;
+  c.to_c = Vec3<float>(l.c[0], l.c[1], l.c[2]) - origin;
+  c.d2 = sqrlen(c.to_c);
+  c.r2 = l.radius * l.radius;
+  c.cos_theta_max = rroot(1.0f - rdiv(c.r2, c.d2));
+  c.inv_len = __builtin_amdgcn_rsqf(c.d2);
+  return c;
+}
+template <bool STATS> RT_DEV float light_pdf_cone(const LightCone& c, Vec3<float> unit_direction, Cnt<STATS>& cnt) {
+  cnt.template inc<ST_LIGHT_PROBES>();
+  cnt.template inc<ST_SPHERE_TESTS>();
+  const float cos_to_centre = dot(unit_direction, c.to_c) * c.inv_len;
+  if (!(c.d2 <= c.r2 || cos_to_centre >= c.cos_theta_max)) return 0.0f;
+  cnt.template inc<ST_SPHERE_HITS>();
+  return rrcp(2.0f * Consts<float>::pi * (1.0f - c.cos_theta_max));
+}
 template <bool STATS>
 RT_DEV float light_pdf_cone(const Light<float>& l, Vec3<float> origin, Vec3<float> unit_direction, Cnt<STATS>& cnt) {
   if (l.tag != LIGHT_SPHERE) return 0.0f;
-  cnt.template inc<ST_LIGHT_PROBES>();
-  cnt.template inc<ST_SPHERE_TESTS>();
-  const Vec3<float> to_c = Vec3<float>(l.c[0], l.c[1], l.c[2]) - origin;
-  const float d2 = sqrlen(to_c), r2 = l.radius * l.radius;
-  const float cos_theta_max = sqrtf(1.0f - rdiv(r2, d2));
-  const float cos_to_centre = dot(unit_direction, to_c) * __builtin_amdgcn_rsqf(d2);
-  if (!(d2 <= r2 || cos_to_centre >= cos_theta_max)) return 0.0f;
-  cnt.template inc<ST_SPHERE_HITS>();
-  return rrcp(2.0f * Consts<float>::pi * (1.0f - cos_theta_max));
+  return light_pdf_cone(light_cone(l, origin), unit_direction, cnt);
 }
 
 template <typename R, bool STATS>
@@ -168,7 +182,7 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
                   RayT<R>& ray, Vec3<R>& thr, Vec3<R>& L, Rng& rng, Cnt<STATS>& cnt) {
   if (m.tag == MAT_DIFFUSE_LIGHT) {  // scatter -> None: return emitted (main.rs:101)
     cnt.template inc<ST_EMITTER>();
-    if (h.front_face) L = L + thr * material_color(sc, m, h);
+    if (h.front_face) L = madd(L, thr, material_color(sc, m, h));
     return false;
   }
   if (m.tag == MAT_DIELECTRIC) {  // material.rs:66-87; emitted is dropped (main.rs:81-83)
@@ -210,6 +224,18 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
   Vec3<R> axis = h.normal;
   R light_radius = R(0), distance_squared = R(1);
   bool no_sample = false;  // a light that is not a Sphere: random() = (1,0,0), no draws
+  // f32, one sphere light (Cornell): Hittable::random and pdf_value need the same geometry of the light as
+  // seen from the hit point — computed once here, for every lane, instead of once in the (divergent)
+  // light-sampling branch and again in the pdf
+  [[maybe_unused]] bool one_cone = false;
+  [[maybe_unused]] LightCone cone{};
+  if constexpr (sizeof(R) == 4) {
+    if (sc.lights_kind == LIGHTS_SINGLE && lights[0].tag == LIGHT_SPHERE) {  // wave-uniform
+      one_cone = true;
+      cone = light_cone(lights[0], h.p);
+    }
+  }
+  R cos_theta_max_sample = R(0);
   if (from_light) {
     uint32_t i = 0;
     if (sc.lights_kind == LIGHTS_LIST) i = rng.below(sc.n_lights);  // list.choose()
@@ -217,23 +243,33 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
     if (l.tag != LIGHT_SPHERE) {
       no_sample = true;
     } else {
-      axis = Vec3<R>(l.c[0], l.c[1], l.c[2]) - h.p;
-      distance_squared = sqrlen(axis);
-      light_radius = l.radius;
+      bool shared = false;
+      if constexpr (sizeof(R) == 4) {
+        if (one_cone) {
+          axis = cone.to_c * cone.inv_len;  // unit
+          cos_theta_max_sample = cone.cos_theta_max;
+          shared = true;
+        }
+      }
+      if (!shared) {
+        axis = Vec3<R>(l.c[0], l.c[1], l.c[2]) - h.p;
+        distance_squared = sqrlen(axis);
+        light_radius = l.radius;
+        cos_theta_max_sample = rroot(R(1) - rdiv(light_radius * light_radius, distance_squared));
+        // f32: the hit normal is unit length already (cube faces, (p-c)/r, rigid maps of those); only the
+        // axis towards a light needs normalising
+        if constexpr (sizeof(R) == 4) axis = normalize(axis);
+      }
     }
   }
   Vec3<R> direction(1, 0, 0);
   if (!no_sample) {
-    // f32: the hit normal is unit length already (cube faces, (p-c)/r, rigid maps of those); only the
-    // axis towards a light needs normalising
-    if constexpr (sizeof(R) == 4)
-      if (from_light) axis = normalize(axis);
     const ONB<R> uvw = sizeof(R) == 4 ? ONB<R>::from_unit_w(axis) : ONB<R>::from_w(axis);
     const R r1 = rng.next<R>();
     const R r2 = rng.next<R>();
     R z, radial;
     if (from_light) {  // alias.rs:84-94
-      z = R(1) + r2 * (rroot(R(1) - rdiv(light_radius * light_radius, distance_squared)) - R(1));
+      z = R(1) + r2 * (cos_theta_max_sample - R(1));
       radial = rroot(R(1) - z * z);
     } else {  // alias.rs:72-82
       z = rroot(R(1) - r2);
@@ -253,7 +289,16 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
   R pdf_value;
   if (have_lights) {
     pdf_value = R(0);
-    pdf_value += R(0.5) * lights_pdf(sc, lights, h.p, direction, unit, cnt);
+    R light_pdf = R(0);
+    bool shared = false;
+    if constexpr (sizeof(R) == 4) {
+      if (one_cone) {
+        light_pdf = light_pdf_cone(cone, unit, cnt);
+        shared = true;
+      }
+    }
+    if (!shared) light_pdf = lights_pdf(sc, lights, h.p, direction, unit, cnt);
+    pdf_value += R(0.5) * light_pdf;
     pdf_value += R(0.5) * cos_pdf;
   } else {
     pdf_value = cos_pdf;
@@ -275,7 +320,7 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
 // viewport ~ 7), so the f32 kernels use the host's f64 (lower_left - origin) instead.
 template <typename R> RT_DEV Vec3<R> primary_direction(const CameraView<R>& cam, R s, R t) {
   if constexpr (sizeof(R) == 4)
-    return cam.ll_rel + s * cam.horizontal + t * cam.vertical;
+    return madd(madd(cam.ll_rel, s, cam.horizontal), t, cam.vertical);
   else
     return cam.lower_left + s * cam.horizontal + t * cam.vertical - cam.origin;
 }
@@ -460,7 +505,7 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : RT_RE
       bool cont;
       if (best == REF_NONE) {  // main.rs:104
         cnt.template inc<ST_MISSES>();
-        L = L + thr * background;
+        L = madd(L, thr, background);
         cont = false;
       } else {
         cnt.template inc<ST_CLOSEST>();
@@ -474,7 +519,7 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : RT_RE
         }
         RT_STAMP(4);
 #ifdef RT_ABL_NOSHADE
-        L = L + thr * h.normal;
+        L = madd(L, thr, h.normal);
         cont = false;
 #else
         cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
@@ -636,7 +681,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
       bool cont;
       if (walk.best == REF_NONE) {  // main.rs:104
         cnt.template inc<ST_MISSES>();
-        L = L + thr * background;
+        L = madd(L, thr, background);
         cont = false;
       } else {
         cnt.template inc<ST_CLOSEST>();
@@ -838,7 +883,7 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
     bool cont;
     if (best == REF_NONE) {  // main.rs:104
       cnt.template inc<ST_MISSES>();
-      L = L + thr * background;
+      L = madd(L, thr, background);
       cont = false;
     } else {
       cnt.template inc<ST_CLOSEST>();
@@ -1015,7 +1060,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SORTED_MIN_WAVES) render_sorted_kern
     if (alive) {
       if (best == REF_NONE) {
         cnt.template inc<ST_MISSES>();
-        L = L + thr * background;
+        L = madd(L, thr, background);
         finish();
       } else {
         cnt.template inc<ST_CLOSEST>();
@@ -1027,7 +1072,7 @@ __global__ void __launch_bounds__(BLOCK, RT_SORTED_MIN_WAVES) render_sorted_kern
         lin_hit_record(sc, s_lin + best * LIN_DWORDS, ray, t, h, mat);
         if (mat.tag == MAT_DIFFUSE_LIGHT) {
           cnt.template inc<ST_EMITTER>();
-          if (h.front_face) L = L + thr * material_color(sc, mat, h);
+          if (h.front_face) L = madd(L, thr, material_color(sc, mat, h));
           finish();
         } else {
           needs_scatter = true;

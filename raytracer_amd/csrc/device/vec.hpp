@@ -86,7 +86,7 @@ template <typename R> RT_DEV Vec3<R> operator/(Vec3<R> a, R s) {
     return {a.x / s, a.y / s, a.z / s};
   }
 }
-// a0 b0 + a1 b1 + a2 b2.  f32: ONE fixed fused form.  Under -ffp-contract=fast the compiler decides per inlined
+// a0 b0 + a1 b1 + a2 b2.  f32: ONE fixed fused form.  Under HIP's default -ffp-contract=fast the compiler decides per inlined
 // copy whether and how to fuse `x*y + z*w + ...`; two walks that reach the same leaf through different code
 // (leaf list, reference-order walk, ordered walk) would then disagree in the last bit of a dot product and,
 // now and then, of t.  f64 (the audit kernels, -ffp-contract=off) keeps the oracle's plain expression.
@@ -97,6 +97,22 @@ template <typename R> RT_DEV R mul_add3(R a0, R b0, R a1, R b1, R a2, R b2) {
     return a0 * b0 + a1 * b1 + a2 * b2;
 }
 template <typename R> RT_DEV R dot(Vec3<R> a, Vec3<R> b) { return mul_add3(a.x, b.x, a.y, b.y, a.z, b.z); }
+// a + s * b and a + b * c per component.  The f32 translation unit is compiled with -ffp-contract=on, which
+// fuses only inside one source expression: the same source gives the same bits in every kernel, but a sum
+// built from Vec3 operators (two function calls) would stay unfused — these helpers fuse it explicitly.
+// f64 (audit kernels, contraction off): the oracle's plain operations.
+template <typename R> RT_DEV Vec3<R> madd(Vec3<R> a, R s, Vec3<R> b) {
+  if constexpr (sizeof(R) == 4)
+    return {__builtin_fmaf(s, b.x, a.x), __builtin_fmaf(s, b.y, a.y), __builtin_fmaf(s, b.z, a.z)};
+  else
+    return a + s * b;
+}
+template <typename R> RT_DEV Vec3<R> madd(Vec3<R> a, Vec3<R> b, Vec3<R> c) {
+  if constexpr (sizeof(R) == 4)
+    return {__builtin_fmaf(b.x, c.x, a.x), __builtin_fmaf(b.y, c.y, a.y), __builtin_fmaf(b.z, c.z, a.z)};
+  else
+    return a + b * c;
+}
 template <typename R> RT_DEV Vec3<R> cross(Vec3<R> a, Vec3<R> b) {
   return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
@@ -113,7 +129,12 @@ template <typename R> RT_DEV Vec3<R> normalize(Vec3<R> a) {
 template <typename R> RT_DEV R comp(Vec3<R> a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
 // alias.rs:101-103
-template <typename R> RT_DEV Vec3<R> reflect(Vec3<R> v, Vec3<R> n) { return v - (R(2) * dot(v, n)) * n; }
+template <typename R> RT_DEV Vec3<R> reflect(Vec3<R> v, Vec3<R> n) {
+  if constexpr (sizeof(R) == 4)
+    return madd(v, -(R(2) * dot(v, n)), n);
+  else
+    return v - (R(2) * dot(v, n)) * n;
+}
 // alias.rs:105-110
 template <typename R> RT_DEV Vec3<R> refract(Vec3<R> v, Vec3<R> n, R etai_over_etat) {
   R cos_theta = rmin(dot(-v, n), R(1));
@@ -164,7 +185,13 @@ template <typename R> struct ONB {
     o.u = cross(o.w, o.v);
     return o;
   }
-  RT_DEV Vec3<R> local(Vec3<R> a) const { return u * a.x + v * a.y + w * a.z; }
+  RT_DEV Vec3<R> local(Vec3<R> a) const {
+    if constexpr (sizeof(R) == 4)
+      return {mul_add3(u.x, a.x, v.x, a.y, w.x, a.z), mul_add3(u.y, a.x, v.y, a.y, w.y, a.z),
+              mul_add3(u.z, a.x, v.z, a.y, w.z, a.z)};
+    else
+      return u * a.x + v * a.y + w * a.z;
+  }
 };
 
 // hittable.rs:533-540

@@ -1,4 +1,4 @@
-// Production precision: f32 kernels for gfx950 (fp contraction on).
+// Production precision: f32 kernels for gfx950 (-ffp-contract=on: fused per source expression, see vec.hpp).
 #define RT_SUFFIX f32
 #define RT_REAL float
 #define RT_HAS_LINEAR 1

@@ -123,9 +123,8 @@ def test_render_f32_within_monte_carlo_noise(name, earthmap):
 def test_leaf_list_path_equals_bvh_walk(name, earthmap):
     """Small scenes take the leaf-list traversal in f32; RT_FLAG_FORCE_BVH walks the BVH instead.
     Same leaves in the same order with the same bounds and the same draws.  The two kernels are
-    separate instantiations (fp contraction differs), so a path whose branch hangs on the last ulp
-    (a bounce ray grazing the surface it starts on) may differ: almost all pixels must agree to
-    rounding, and the totals must agree closely."""
+    separate instantiations of the same source, built with -ffp-contract=on (fused per source expression,
+    not per inlined copy): they compute the same bits and follow the same paths."""
     hs, ds, os_, h, depth = _pair(name, earthmap)
     a, sa = ds.render(W, h, 32, depth, seed=5, stats=True)
     b, sb = ds.render(W, h, 32, depth, seed=5, stats=True, force_bvh=True)
