@@ -75,8 +75,13 @@ enum rt_texture_tag {   /* texture.rs:7-14 */
   RT_TEX_CHECKER = 1,   /* odd / even = texture indices (may nest) */
   RT_TEX_IMAGE = 2,     /* texel_offset (bytes into texels), width, height; RGB8 row-major */
   RT_TEX_NORMAL = 3,
-  RT_TEX_UV = 4
+  RT_TEX_UV = 4,
+  RT_TEX_NOISE = 5      /* EXTENSION, no counterpart in the reference: Perlin marble of "Ray Tracing:
+                           The Next Week", value = 0.5 (1 + sin(scale z + 10 turb(p, 7))) on all channels;
+                           color[0] = scale; texel_offset (multiple of 8) = byte offset into texels of its table:
+                           256 unit gradient vectors as f64 xyz (6144 B), then perm_x, perm_y, perm_z (256 B each) */
 };
+#define RT_NOISE_TABLE_BYTES (256u * 3u * 8u + 3u * 256u)
 
 enum rt_light_tag {     /* hittable.rs:477-515: only Sphere is importance-sampled */
   RT_LIGHT_SPHERE = 0,  /* light_sphere = centre xyz, radius */

@@ -20,14 +20,15 @@ typedef struct rth_scene rth_scene; /* a flattened scene + its camera, host memo
 
 typedef struct rth_scene_opts {
   int32_t scene_id;        /* main.rs:117-124: 0 random, 1 two_spheres, 2 earth, 3 simple_light, 4 cube_scene,
-                              other small_scene; plus 6 cornell_box, 7 bvh_stress, 8 final_scene */
+                              other small_scene; plus 6 cornell_box, 7 bvh_stress, 8 final_scene, 9 mixed_scene (parity-test
+                              generator), and the extensions 10 perlin_spheres, 11 final_scene with the Perlin sphere */
   int32_t rotate_bbox;     /* -1 scene default, 0 reference (Q3), 1 correct */
   double aspect_ratio;     /* main.rs:41-42 */
   uint64_t scene_seed;     /* scenes.rs:64 uses 5 */
   uint64_t bvh_seed;       /* split-axis stream (hittable.rs:161 is unseeded in the reference) */
   uint32_t n;              /* scene 7: number of random spheres */
   uint32_t tex_width, tex_height;
-  const uint8_t* texels;   /* decoded assets/earthmap.jpg, RGB8 row-major (scenes 2, 4, 8) */
+  const uint8_t* texels;   /* decoded assets/earthmap.jpg, RGB8 row-major (scenes 2, 4, 8, 11; 9 optionally) */
 } rth_scene_opts;
 
 /* Replaces main.rs:117-150: scene function, Hittable::new_bvh, lights fold, Camera::new. */

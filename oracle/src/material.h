@@ -5,15 +5,75 @@
 #pragma once
 #include <cstdint>
 #include <memory>
+#include <utility>
 #include <vector>
 
 #include "alias.h"
+#include "philox.h"
 
 namespace orc {
 
+// ---- EXTENSION (no counterpart in the reference): Perlin noise of "Ray Tracing: The
+// Next Week" (gradient noise with trilinear Hermite interpolation, turbulence of depth 7), so that the
+// final-scene composition can carry its marble sphere.  Table = 256 random unit vectors + three permutations.
+struct NoiseTable {
+  double vec[256][3];
+  uint8_t perm[3][256];
+
+  // draw order: 256 x (x, y, z in [-1,1)), then for each of the three permutations the 255 swap targets
+  // of a Fisher-Yates shuffle running from the top: target = floor(next * (i + 1)), i = 255 .. 1
+  static std::shared_ptr<const NoiseTable> make(Rng& rng) {
+    auto t = std::make_shared<NoiseTable>();
+    for (int i = 0; i < 256; ++i) {
+      const double x = rng.range(-1.0, 1.0);
+      const double y = rng.range(-1.0, 1.0);
+      const double z = rng.range(-1.0, 1.0);
+      const double len = std::sqrt(x * x + y * y + z * z);
+      t->vec[i][0] = x / len;
+      t->vec[i][1] = y / len;
+      t->vec[i][2] = z / len;
+    }
+    for (int a = 0; a < 3; ++a) {
+      for (int i = 0; i < 256; ++i) t->perm[a][i] = (uint8_t)i;
+      for (int i = 255; i > 0; --i) {
+        const int target = (int)(rng.next_f64() * (double)(i + 1));
+        std::swap(t->perm[a][i], t->perm[a][target]);
+      }
+    }
+    return t;
+  }
+  double noise(V3 p) const {
+    const double fx = std::floor(p.x), fy = std::floor(p.y), fz = std::floor(p.z);
+    const double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    const double uu = u * u * (3.0 - 2.0 * u), vv = v * v * (3.0 - 2.0 * v), ww = w * w * (3.0 - 2.0 * w);
+    double accum = 0.0;
+    for (int di = 0; di < 2; ++di)
+      for (int dj = 0; dj < 2; ++dj)
+        for (int dk = 0; dk < 2; ++dk) {
+          const int idx = perm[0][(i + di) & 255] ^ perm[1][(j + dj) & 255] ^ perm[2][(k + dk) & 255];
+          const double wx = u - di, wy = v - dj, wz = w - dk;
+          const double d = vec[idx][0] * wx + vec[idx][1] * wy + vec[idx][2] * wz;
+          accum += (di ? uu : 1.0 - uu) * (dj ? vv : 1.0 - vv) * (dk ? ww : 1.0 - ww) * d;
+        }
+    return accum;
+  }
+  double turb(V3 p) const {
+    double accum = 0.0, weight = 1.0;
+    for (int o = 0; o < 7; ++o) {
+      accum += weight * noise(p);
+      weight *= 0.5;
+      p = 2.0 * p;
+    }
+    return std::fabs(accum);
+  }
+};
+
 // ---- texture.rs ------------------------------------------------------------------------
 struct Texture {
-  enum Kind { Solid, Checker, Image, Normal, UV } kind = Solid;
+  enum Kind { Solid, Checker, Image, Normal, UV, Noise } kind = Solid;
+  std::shared_ptr<const NoiseTable> noise_table;  // Noise (extension)
+  double noise_scale = 1.0;
   V3 color;                                   // Solid
   std::shared_ptr<const Texture> odd, even;   // Checker
   std::shared_ptr<const std::vector<uint8_t>> texels;  // Image: RGB8 row-major
@@ -55,6 +115,13 @@ struct Texture {
     t.kind = UV;
     return t;
   }
+  static Texture noise(std::shared_ptr<const NoiseTable> table, double scale) {  // extension
+    Texture t;
+    t.kind = Noise;
+    t.noise_table = std::move(table);
+    t.noise_scale = scale;
+    return t;
+  }
 
   // texture.rs:33-69
   V3 value(V2 uv, V3 p, V3 normal) const {
@@ -90,6 +157,10 @@ struct Texture {
         return {std::fabs(normal.x), std::fabs(normal.y), std::fabs(normal.z)};
       case UV:
         return {uv.x, uv.y, 0.0};
+      case Noise: {  // marble: 0.5 (1 + sin(scale z + 10 turb(p)))
+        const double m = 0.5 * (1.0 + std::sin(noise_scale * p.z + 10.0 * noise_table->turb(p)));
+        return {m, m, m};
+      }
     }
     return {};
   }

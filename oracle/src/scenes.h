@@ -247,7 +247,7 @@ inline void bvh_stress(SceneDef& s, uint64_t seed, uint32_t n) {
 // a 20×20 floor of Cubes, a Sphere light, a MovingSphere, glass, metal, two
 // ConstantMedium(Sphere) volumes, an earthmap sphere, a checker sphere in place of Perlin
 // noise, and 1000 small white spheres each wrapped Translate(Rotate(Sphere)).
-inline void final_scene(SceneDef& s, const SceneSpec& spec) {
+inline void final_scene(SceneDef& s, const SceneSpec& spec, bool perlin = false) {
   Rng rng = scene_rng(spec.scene_seed, 0);
   Material ground = Material::lambertian(V3(0.48, 0.83, 0.53));
   const int boxes_per_side = 20;
@@ -277,9 +277,12 @@ inline void final_scene(SceneDef& s, const SceneSpec& spec) {
   s.world.push_back(Hittable::new_constant_medium(
       Hittable::new_sphere(V3(0.0, 0.0, 0.0), 5000.0, Material::dielectric(1.5)), 0.0001, V3(1.0, 1.0, 1.0)));
   s.world.push_back(Hittable::new_sphere(V3(400.0, 200.0, 400.0), 100.0, Material::lambertian_tex(earth_texture(spec))));
+  // scene 8 (BASELINE config 3) puts a checker here; scene 11 the book's Perlin marble (extension, scene stream 2)
+  Rng noise_rng = scene_rng(spec.scene_seed, 2);
   s.world.push_back(Hittable::new_sphere(
       V3(220.0, 280.0, 300.0), 80.0,
-      Material::lambertian_tex(Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9)))));
+      Material::lambertian_tex(perlin ? Texture::noise(NoiseTable::make(noise_rng), 0.1)
+                                      : Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9)))));
   Material white = Material::lambertian(V3(0.73, 0.73, 0.73));
   for (int j = 0; j < 1000; ++j) {
     double px = rng.range(0.0, 165.0);
@@ -305,13 +308,15 @@ inline void mixed_scene(SceneDef& s, const SceneSpec& spec) {
   const uint64_t seed = spec.scene_seed;
   const uint32_t n = spec.n;
   Rng rng = scene_rng(seed, 0);
+  Rng noise_rng = scene_rng(seed, 2);
+  std::shared_ptr<const NoiseTable> noise_table = NoiseTable::make(noise_rng);  // one table for the scene's noise textures
   // the ground's top face is NOT at y = 0: a checker (sin(10 y)) on a plane at a zero of the sine picks its
   // colour from the rounding noise of p.y, differently in every arithmetic
   s.world.push_back(Hittable::new_cube(V3(-40.0, -1.1, -40.0), V3(40.0, -0.1, 40.0),
                                        Material::lambertian_tex(Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9)))));
   for (uint32_t i = 0; i < n; ++i) {
     const int shape = (int)(rng.next_f64() * 14.0);
-    const int mat = (int)(rng.next_f64() * 8.0);
+    const int mat = (int)(rng.next_f64() * 9.0);
     const double x = rng.range(-9.0, 9.0);
     const double y = rng.range(0.4, 3.5);
     const double z = rng.range(-9.0, 9.0);
@@ -334,7 +339,8 @@ inline void mixed_scene(SceneDef& s, const SceneSpec& spec) {
       case 4: m = Material::metal(V3(0.5 + 0.5 * a1, 0.5 + 0.5 * a2, 0.5 + 0.5 * a3), fuzz); break;
       case 5: m = Material::dielectric(1.5); break;
       case 6: m = Material::isotropic(col); break;
-      default: m = Material::lambertian_tex(spec.texels ? earth_texture(spec) : Texture::uv()); break;
+      case 7: m = Material::lambertian_tex(spec.texels ? earth_texture(spec) : Texture::uv()); break;
+      default: m = Material::lambertian_tex(Texture::noise(noise_table, 1.0 + 3.0 * a1)); break;  // extension
     }
     const double density = 0.5 + 2.0 * a2;
     const V3 zero(0.0, 0.0, 0.0);
@@ -389,6 +395,14 @@ inline void mixed_scene(SceneDef& s, const SceneSpec& spec) {
   s.rotate_bbox = (seed & 1) ? RotateBBox::Correct : RotateBBox::Reference;
 }
 
+// Scene 10 (extension): "two_perlin_spheres" of The Next Week under the reference's fixed camera and sky.
+inline void perlin_spheres(SceneDef& s, uint64_t seed) {
+  Rng noise_rng = scene_rng(seed, 2);
+  Texture marble = Texture::noise(NoiseTable::make(noise_rng), 4.0);
+  s.world.push_back(Hittable::new_sphere(V3(0.0, -1000.0, 0.0), 1000.0, Material::lambertian_tex(marble)));
+  s.world.push_back(Hittable::new_sphere(V3(0.0, 2.0, 0.0), 2.0, Material::lambertian_tex(marble)));
+}
+
 // main.rs:117-124 plus the three extra ids
 inline SceneDef build_scene_def(const SceneSpec& spec) {
   SceneDef s;
@@ -404,6 +418,8 @@ inline SceneDef build_scene_def(const SceneSpec& spec) {
     case 7: bvh_stress(s, spec.scene_seed, spec.n); break;
     case 8: final_scene(s, spec); break;
     case 9: mixed_scene(s, spec); break;
+    case 10: perlin_spheres(s, spec.scene_seed); break;
+    case 11: final_scene(s, spec, true); break;
     default: small_scene(s); break;
   }
   return s;

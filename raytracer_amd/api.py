@@ -12,9 +12,9 @@ _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 
 SCENE_IDS = {
     "random_scene": 0, "two_spheres": 1, "earth": 2, "simple_light": 3, "cube_scene": 4, "small_scene": 5,
-    "cornell_box": 6, "bvh_stress": 7, "final_scene": 8, "mixed_scene": 9,
+    "cornell_box": 6, "bvh_stress": 7, "final_scene": 8, "mixed_scene": 9, "perlin_spheres": 10, "final_scene_perlin": 11,
 }
-_NEEDS_EARTHMAP = (2, 4, 8)
+_NEEDS_EARTHMAP = (2, 4, 8, 11)
 
 
 def _ptr(a):

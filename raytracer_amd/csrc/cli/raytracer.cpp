@@ -53,10 +53,11 @@ const char* USAGE =
     "        --scene-seed <n>      scene generator seed (scenes.rs:64 uses 5) [default: 5]\n"
     "        --bvh-seed <n>        BVH split-axis stream [default: 7]\n"
     "        --n <n>               scene 7 (bvh_stress): number of spheres\n"
-    "        --earthmap <file>     binary PPM (P6, maxval 255) of the earth texture, scenes 2, 4, 8\n"
+    "        --earthmap <file>     binary PPM (P6, maxval 255) of the earth texture, scenes 2, 4, 8, 11\n"
     "                              [default: assets/earthmap.ppm]\n"
     "    scenes: 0 random_scene, 1 two_spheres, 2 earth, 3 simple_light, 4 cube_scene, 6 cornell_box,\n"
-    "            7 bvh_stress, 8 final_scene, anything else small_scene (main.rs:117-124)\n";
+    "            7 bvh_stress, 8 final_scene, 9 mixed_scene (test generator), 10 perlin_spheres and\n"
+    "            11 final_scene with the Perlin sphere (extensions), anything else small_scene (main.rs:117-124)\n";
 
 [[noreturn]] void usage_error(const std::string& msg) {
   std::fprintf(stderr, "error: %s\n\nUSAGE:\n    raytracer [OPTIONS]\n\nFor more information try --help\n", msg.c_str());
@@ -207,7 +208,7 @@ int main(int argc, char** argv) {
   ro.scene.bvh_seed = o.bvh_seed;
   ro.scene.n = o.n;
   std::vector<uint8_t> texels;
-  if (o.scene == 2 || o.scene == 4 || o.scene == 8) {  // Texture::new_image (texture.rs:25-31, scenes.rs:126)
+  if (o.scene == 2 || o.scene == 4 || o.scene == 8 || o.scene == 11) {  // Texture::new_image (texture.rs:25-31, scenes.rs:126)
     if (!read_ppm(o.earthmap, texels, ro.scene.tex_width, ro.scene.tex_height)) {
       std::fprintf(stderr,
                    "error: scene %u needs the earth texture: cannot read '%s' as a binary PPM (P6, maxval 255).\n"

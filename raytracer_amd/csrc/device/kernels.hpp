@@ -27,6 +27,40 @@ constexpr int BLOCK = 256;
 #define RT_REFILL_MIN_WAVES 5
 #endif
 
+// ---- EXTENSION (rt.h RT_TEX_NOISE, no counterpart in the reference): Perlin noise of "The Next Week" ---------
+// tab: 256 unit vectors (f64 xyz) then perm_x, perm_y, perm_z.  Same expression order as the oracle's
+// NoiseTable (the f64 audit kernel reproduces it bit for bit).
+template <typename R> RT_DEV R perlin_noise(const uint8_t* tab, Vec3<R> p) {
+  const double* vec = reinterpret_cast<const double*>(tab);
+  const uint8_t* perm = tab + 256 * 3 * sizeof(double);
+  const R fx = __builtin_floor(p.x), fy = __builtin_floor(p.y), fz = __builtin_floor(p.z);
+  const R u = p.x - fx, v = p.y - fy, w = p.z - fz;
+  const int i = (int)fx, j = (int)fy, k = (int)fz;
+  const R uu = u * u * (R(3) - R(2) * u), vv = v * v * (R(3) - R(2) * v), ww = w * w * (R(3) - R(2) * w);
+  R accum = R(0);
+#pragma unroll
+  for (int di = 0; di < 2; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+      for (int dk = 0; dk < 2; ++dk) {
+        const uint32_t idx = perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)];
+        const R wx = u - R(di), wy = v - R(dj), wz = w - R(dk);
+        const R d = (R)vec[3 * idx] * wx + (R)vec[3 * idx + 1] * wy + (R)vec[3 * idx + 2] * wz;
+        accum += (di ? uu : R(1) - uu) * (dj ? vv : R(1) - vv) * (dk ? ww : R(1) - ww) * d;
+      }
+  return accum;
+}
+template <typename R> RT_DEV R perlin_turb(const uint8_t* tab, Vec3<R> p) {
+  R accum = R(0), weight = R(1);
+  for (int o = 0; o < 7; ++o) {
+    accum += weight * perlin_noise(tab, p);
+    weight *= R(0.5);
+    p = R(2) * p;
+  }
+  return rabs(accum);
+}
+
 // ---- texture.rs:33-69 ---------------------------------------------------------------------
 template <typename R>
 RT_DEV Vec3<R> texture_value(const SceneView<R>& sc, uint32_t idx, Vec2<R> uv, Vec3<R> p, Vec3<R> normal) {
@@ -51,6 +85,10 @@ RT_DEV Vec3<R> texture_value(const SceneView<R>& sc, uint32_t idx, Vec2<R> uv, V
       const uint8_t* px = sc.texels + t.texel_offset + 3ull * ((uint64_t)y * t.width + x);
       const R color_scale = R(1) / R(255);
       return Vec3<R>((R)px[0] * color_scale, (R)px[1] * color_scale, (R)px[2] * color_scale);
+    }
+    if (t.tag == TEX_NOISE) {
+      const R m = R(0.5) * (R(1) + rsin(t.color[0] * p.z + R(10) * perlin_turb(sc.texels + t.texel_offset, p)));
+      return Vec3<R>(m, m, m);
     }
     if (t.tag == TEX_NORMAL) return Vec3<R>(rabs(normal.x), rabs(normal.y), rabs(normal.z));
     return Vec3<R>(uv.x, uv.y, R(0));  // TEX_UV

@@ -13,7 +13,7 @@ constexpr uint32_t LEAF_SPHERE = 0, LEAF_MSPHERE = 1, LEAF_CUBE = 2, LEAF_COMPLE
 constexpr uint32_t OP_TRANSLATE = 0, OP_ROTATE = 1, OP_MEDIUM = 2;
 constexpr uint32_t MAT_LAMBERTIAN = 0, MAT_DIELECTRIC = 1, MAT_METAL = 2, MAT_DIFFUSE_LIGHT = 3,
                    MAT_ISOTROPIC = 4;
-constexpr uint32_t TEX_SOLID = 0, TEX_CHECKER = 1, TEX_IMAGE = 2, TEX_NORMAL = 3, TEX_UV = 4;
+constexpr uint32_t TEX_SOLID = 0, TEX_CHECKER = 1, TEX_IMAGE = 2, TEX_NORMAL = 3, TEX_UV = 4, TEX_NOISE = 5;
 constexpr uint32_t LIGHT_SPHERE = 0, LIGHT_OTHER = 1;
 constexpr uint32_t LIGHTS_NONE = 0, LIGHTS_SINGLE = 1, LIGHTS_LIST = 2;
 

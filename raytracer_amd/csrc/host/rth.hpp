@@ -54,9 +54,16 @@ Stream scene_stream(uint64_t scene_seed, uint32_t stream);  // replaces StdRng::
 int bvh_axis(uint64_t bvh_seed, uint32_t call);             // replaces gen_range(0..3) at hittable.rs:161
 
 // ---- texture.rs:7-31 ------------------------------------------------------------------
+struct Stream;
 struct Texture {
-  enum Kind { Solid, Checker, Image, Normal, UV } kind = Solid;
+  enum Kind { Solid, Checker, Image, Normal, UV, Noise } kind = Solid;
   Color color;
+  // EXTENSION (no counterpart in the reference): Perlin marble of "The Next Week".  The table is the byte
+  // image rt.h documents for RT_TEX_NOISE: 256 unit vectors (f64 xyz) followed by three 256-entry permutations.
+  std::shared_ptr<const std::vector<uint8_t>> noise_table;
+  double noise_scale = 1.0;
+  static std::shared_ptr<const std::vector<uint8_t>> make_noise_table(Stream& r);
+  static Texture new_noise(std::shared_ptr<const std::vector<uint8_t>> table, double scale);
   std::shared_ptr<const Texture> odd, even;
   std::shared_ptr<const std::vector<uint8_t>> texels;  // RGB8 row-major, already decoded
   uint32_t width = 0, height = 0;
@@ -154,7 +161,7 @@ SceneDef simple_light();                         // scenes.rs:133-175
 SceneDef cube_scene(const SceneOpts& o);         // scenes.rs:177-192
 SceneDef cornell_box();                          // BASELINE.json configs[1], [4]
 SceneDef bvh_stress(uint64_t seed, uint32_t n);  // BASELINE.json configs[3]
-SceneDef final_scene(const SceneOpts& o);        // BASELINE.json configs[2]
+SceneDef final_scene(const SceneOpts& o, bool perlin = false);  // BASELINE.json configs[2]; perlin: scene 11 (extension)
 SceneDef scene_by_id(const SceneOpts& o);        // main.rs:117-124 (+ ids 6, 7, 8)
 
 // The flat scene: owns every array an rt_scene_desc points into.

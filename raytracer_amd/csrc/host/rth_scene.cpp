@@ -117,6 +117,34 @@ Texture Texture::new_uv() {
   t.kind = UV;
   return t;
 }
+// Extension: the gradient table of the Perlin texture, laid out as the device reads it (rt.h, RT_TEX_NOISE).
+// Draws: 256 x (x, y, z in [-1, 1)), then per permutation the Fisher-Yates targets floor(next * (i + 1)) for
+// i = 255 .. 1 — the same list the oracle's NoiseTable::make consumes.
+std::shared_ptr<const std::vector<uint8_t>> Texture::make_noise_table(Stream& r) {
+  auto bytes = std::make_shared<std::vector<uint8_t>>(RT_NOISE_TABLE_BYTES);
+  double* vec = reinterpret_cast<double*>(bytes->data());
+  uint8_t* perm = bytes->data() + 256 * 3 * sizeof(double);
+  for (int i = 0; i < 256; ++i) {
+    const double x = r.range(-1.0, 1.0), y = r.range(-1.0, 1.0), z = r.range(-1.0, 1.0);
+    const double len = std::sqrt(x * x + y * y + z * z);
+    vec[3 * i] = x / len;
+    vec[3 * i + 1] = y / len;
+    vec[3 * i + 2] = z / len;
+  }
+  for (int axis = 0; axis < 3; ++axis) {
+    uint8_t* p = perm + 256 * axis;
+    for (int i = 0; i < 256; ++i) p[i] = (uint8_t)i;
+    for (int i = 255; i > 0; --i) std::swap(p[i], p[(int)(r.next_f64() * (double)(i + 1))]);
+  }
+  return bytes;
+}
+Texture Texture::new_noise(std::shared_ptr<const std::vector<uint8_t>> table, double scale) {
+  Texture t;
+  t.kind = Noise;
+  t.noise_table = std::move(table);
+  t.noise_scale = scale;
+  return t;
+}
 
 Material Material::new_lambertian(Color albedo) { return new_lambertian_with_texture(Texture::new_solid(albedo)); }
 Material Material::new_lambertian_with_texture(Texture t) {
@@ -435,6 +463,21 @@ struct Flattener {
       case Texture::UV:
         fs.tex_tag[me] = RT_TEX_UV;
         break;
+      case Texture::Noise: {  // extension: the table travels in the texel blob, 8-byte aligned
+        fs.tex_tag[me] = RT_TEX_NOISE;
+        fs.tex_color[3 * (size_t)me] = t.noise_scale;
+        uint64_t off = ~0ull;
+        for (auto& known : images)
+          if (known.first == t.noise_table.get()) off = known.second;
+        if (off == ~0ull) {
+          fs.texels.resize((fs.texels.size() + 7) / 8 * 8, 0);
+          off = fs.texels.size();
+          fs.texels.insert(fs.texels.end(), t.noise_table->begin(), t.noise_table->end());
+          images.emplace_back(t.noise_table.get(), off);
+        }
+        fs.tex_texel_offset[me] = off;
+        break;
+      }
     }
     return me;
   }

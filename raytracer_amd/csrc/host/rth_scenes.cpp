@@ -165,7 +165,7 @@ SceneDef bvh_stress(uint64_t seed, uint32_t n) {
   return s;
 }
 
-SceneDef final_scene(const SceneOpts& o) {
+SceneDef final_scene(const SceneOpts& o, bool perlin) {
   SceneDef s;
   Stream r = scene_stream(o.scene_seed, 0);
   const Material ground = Material::new_lambertian(Color(0.48, 0.83, 0.53));
@@ -191,9 +191,11 @@ SceneDef final_scene(const SceneOpts& o) {
   s.world.push_back(Hittable::new_constant_medium(
       Hittable::new_sphere(Point(0.0, 0.0, 0.0), 5000.0, Material::new_dielectric(1.5)), 0.0001, Color(1.0, 1.0, 1.0)));
   s.world.push_back(Hittable::new_sphere(Point(400.0, 200.0, 400.0), 100.0, Material::new_lambertian_with_texture(earthmap(o))));
+  Stream noise_stream = scene_stream(o.scene_seed, 2);  // scene 11 only: the book's marble instead of the checker
   s.world.push_back(Hittable::new_sphere(
       Point(220.0, 280.0, 300.0), 80.0,
-      Material::new_lambertian_with_texture(Texture::new_checker_color(Color(0.2, 0.3, 0.1), Color(0.9, 0.9, 0.9)))));
+      Material::new_lambertian_with_texture(perlin ? Texture::new_noise(Texture::make_noise_table(noise_stream), 0.1)
+                                                   : Texture::new_checker_color(Color(0.2, 0.3, 0.1), Color(0.9, 0.9, 0.9)))));
   const Material white = Material::new_lambertian(Color(0.73, 0.73, 0.73));
   for (int j = 0; j < 1000; ++j) {
     const double x = r.range(0.0, 165.0), y = r.range(0.0, 165.0), z = r.range(0.0, 165.0);
@@ -215,12 +217,14 @@ SceneDef mixed_scene(const SceneOpts& o) {
   const uint64_t seed = o.scene_seed;
   const uint32_t n = o.n;
   Stream r = scene_stream(seed, 0);
+  Stream noise_stream = scene_stream(seed, 2);
+  const auto noise_table = Texture::make_noise_table(noise_stream);  // shared by the scene's noise textures
   const Color pale(0.9, 0.9, 0.9);
   s.world.push_back(Hittable::new_cube(Point(-40.0, -1.1, -40.0), Point(40.0, -0.1, 40.0),
                                        Material::new_lambertian_with_texture(Texture::new_checker_color(Color(0.2, 0.3, 0.1), pale))));
   for (uint32_t i = 0; i < n; ++i) {
     const int shape_class = (int)(r.next_f64() * 14.0);
-    const int material_class = (int)(r.next_f64() * 8.0);
+    const int material_class = (int)(r.next_f64() * 9.0);
     const double px = r.range(-9.0, 9.0), py = r.range(0.4, 3.5), pz = r.range(-9.0, 9.0);
     const double size = r.range(0.25, 0.9);
     const double degrees = r.range(-60.0, 60.0);
@@ -240,7 +244,8 @@ SceneDef mixed_scene(const SceneOpts& o) {
     else if (material_class == 4) surface = Material::new_metal(Color(0.5 + 0.5 * c1, 0.5 + 0.5 * c2, 0.5 + 0.5 * c3), fuzz);
     else if (material_class == 5) surface = Material::new_dielectric(1.5);
     else if (material_class == 6) surface = Material::new_isotropic(tint);
-    else surface = Material::new_lambertian_with_texture(o.texels ? earthmap(o) : Texture::new_uv());
+    else if (material_class == 7) surface = Material::new_lambertian_with_texture(o.texels ? earthmap(o) : Texture::new_uv());
+    else surface = Material::new_lambertian_with_texture(Texture::new_noise(noise_table, 1.0 + 3.0 * c1));  // extension
     const double density = 0.5 + 2.0 * c2;
     const double turn = to_radians(degrees);
     Hittable h;
@@ -299,6 +304,16 @@ SceneDef mixed_scene(const SceneOpts& o) {
   return s;
 }
 
+// Scene 10 (extension): the two Perlin spheres of "The Next Week", reference camera and sky.
+SceneDef perlin_spheres(uint64_t seed) {
+  SceneDef s = with_reference_view();
+  Stream noise_stream = scene_stream(seed, 2);
+  const Texture marble = Texture::new_noise(Texture::make_noise_table(noise_stream), 4.0);
+  s.world.push_back(Hittable::new_sphere(Point(0.0, -1000.0, 0.0), 1000.0, Material::new_lambertian_with_texture(marble)));
+  s.world.push_back(Hittable::new_sphere(Point(0.0, 2.0, 0.0), 2.0, Material::new_lambertian_with_texture(marble)));
+  return s;
+}
+
 SceneDef scene_by_id(const SceneOpts& o) {
   switch (o.scene_id) {
     case 0: return random_scene(o.scene_seed);
@@ -310,6 +325,8 @@ SceneDef scene_by_id(const SceneOpts& o) {
     case 7: return bvh_stress(o.scene_seed, o.n);
     case 8: return final_scene(o);
     case 9: return mixed_scene(o);
+    case 10: return perlin_spheres(o.scene_seed);
+    case 11: return final_scene(o, true);
     default: return small_scene();  // main.rs:123
   }
 }

@@ -537,7 +537,11 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
 
   // textures: tags, checker children in range and acyclic (children must have a larger index)
   for (uint32_t i = 0; i < d->n_textures; ++i) {
-    NEED(d->tex_tag[i] <= RT_TEX_UV, "bad texture tag");
+    NEED(d->tex_tag[i] <= RT_TEX_NOISE, "bad texture tag");
+    if (d->tex_tag[i] == RT_TEX_NOISE) {  // extension: the gradient table lives in the texel blob
+      NEED(d->tex_texel_offset[i] % 8 == 0, "noise table must be 8-byte aligned inside texels");
+      NEED(d->tex_texel_offset[i] + RT_NOISE_TABLE_BYTES <= d->n_texel_bytes, "noise table outside texels");
+    }
     if (d->tex_tag[i] == RT_TEX_CHECKER)
       NEED(d->tex_odd[i] < d->n_textures && d->tex_even[i] < d->n_textures && d->tex_odd[i] > i && d->tex_even[i] > i,
            "checker children must be textures with a larger index");

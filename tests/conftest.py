@@ -24,6 +24,9 @@ SCENES = {
     "cornell_box": (6, 1.0, 0, 50),
     "bvh_stress": (7, 16.0 / 9.0, 20000, 50),
     "final_scene": (8, 1.0, 0, 50),
+    # extensions: Perlin noise texture
+    "perlin_spheres": (10, 1.5, 0, 5),
+    "final_scene_perlin": (11, 1.0, 0, 50),
 }
 
 

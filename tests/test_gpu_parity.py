@@ -68,7 +68,7 @@ def test_primary_hits_f32(name, earthmap):
 
 
 @pytest.mark.parametrize("name", ["random_scene", "two_spheres", "earth", "simple_light", "cube_scene",
-                                  "small_scene", "cornell_box", "final_scene"])
+                                  "small_scene", "cornell_box", "final_scene", "perlin_spheres", "final_scene_perlin"])
 def test_render_f64_follows_oracle_path_for_path(name, earthmap):
     hs, ds, os_, h, depth = _pair(name, earthmap)
     spp = 8
@@ -93,7 +93,7 @@ def _psnr(a, b):
 
 
 @pytest.mark.parametrize("name", ["random_scene", "simple_light", "cornell_box", "earth", "small_scene", "final_scene",
-                                  "bvh_stress"])
+                                  "bvh_stress", "perlin_spheres"])
 def test_render_f32_within_monte_carlo_noise(name, earthmap):
     """f32 production kernel vs oracle, different seeds, matched spp: the difference of two
     independent estimates must look like noise of the measured per-pixel variance."""
