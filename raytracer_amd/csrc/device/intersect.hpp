@@ -569,8 +569,15 @@ RT_DEV bool lin_prim_t(const float* rec, uint32_t flags, Vec3<float> o, Vec3<flo
 
 // MEDIA = false compiles the loop without the constant-medium arm, so the RNG state is not
 // loop-carried (no per-iteration register copies) in scenes that have no medium.
+// the three LINF_* bits of every record, bit k = record k: kernel arguments (SceneView), i.e. scalar registers
+struct LinMasks {
+  uint32_t xf, cube, medium;
+};
+template <typename SV> RT_DEV LinMasks lin_masks(const SV& sc) {
+  return LinMasks{sc.linear_xf_mask, sc.linear_cube_mask, sc.linear_medium_mask};
+}
 template <bool STATS, bool MEDIA>
-RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, const RayT<float>& r, float t_min, Rng& rng,
+RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, LinMasks masks, const RayT<float>& r, float t_min, Rng& rng,
                             float& closest, uint32_t& best_k, Cnt<STATS>& cnt) {
   closest = Consts<float>::inf;
   best_k = REF_NONE;
@@ -578,7 +585,10 @@ RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, const RayT<floa
   const float a0 = sqrlen(r.d);
   for (uint32_t k = 0; k < n_linear; ++k) {
     const float* rec = lin + k * LIN_DWORDS;
-    const uint32_t flags = __float_as_uint(rec[LIN_FLAGS]);
+    // wave-uniform, from scalar registers (reading rec[LIN_FLAGS] costs an LDS round trip and a
+    // v_readfirstlane per leaf before the first branch can be taken)
+    const uint32_t flags = ((masks.xf >> k) & 1u) * LINF_XF | ((masks.cube >> k) & 1u) * LINF_CUBE |
+                           ((masks.medium >> k) & 1u) * LINF_MEDIUM;
     float t;
     bool h;
     // one leaf in a given frame; instantiated twice (world frame / the record's rigid map) so the

@@ -525,9 +525,9 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : RT_RE
       uint32_t best;
       if constexpr (LINEAR) {
         if (sc.linear_has_media)  // wave-uniform
-          traverse_linear<STATS, true>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+          traverse_linear<STATS, true>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
         else
-          traverse_linear<STATS, false>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+          traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
       } else if constexpr (TRAV == TRAV_ORDERED) {  // run-to-completion form of the ordered walk (A/B baseline)
         OrderedWalk walk;
         bool more = walk.start(sc, ray);
@@ -914,9 +914,9 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
     R t;
     uint32_t best;
     if (sc.linear_has_media)  // wave-uniform
-      traverse_linear<STATS, true>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+      traverse_linear<STATS, true>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
     else
-      traverse_linear<STATS, false>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+      traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
     RT_STAMP(4);  // leaf-list walk
     bool cont;
     if (best == REF_NONE) {  // main.rs:104
@@ -1084,9 +1084,9 @@ __global__ void __launch_bounds__(BLOCK, RT_SORTED_MIN_WAVES) render_sorted_kern
       ray.d = rd;
       ray.time = R(0);  // leaf-list scenes hold no moving sphere
       if (sc.linear_has_media)  // wave-uniform
-        traverse_linear<STATS, true>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+        traverse_linear<STATS, true>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
       else
-        traverse_linear<STATS, false>(s_lin, sc.n_linear, ray, R(0.001), rng, t, best, cnt);
+        traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
     }
     // (C) the winner's HitRecord; misses and emitters end here (main.rs:101-104), the rest needs scatter
     bool needs_scatter = false;
@@ -1273,7 +1273,7 @@ __global__ void __launch_bounds__(BLOCK) primary_kernel(SceneView<R> sc, CameraV
     best = walk.best;
   } else if constexpr (TRAV == TRAV_LINEAR) {
     uint32_t k;
-    traverse_linear<false, true>(reinterpret_cast<const float*>(sc.linear_rec), sc.n_linear, ray, R(0.001), rng, t, k, cnt);
+    traverse_linear<false, true>(reinterpret_cast<const float*>(sc.linear_rec), sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, k, cnt);
     best = k == REF_NONE ? REF_NONE : sc.linear_rec[k * LIN_DWORDS + LIN_REF];
   } else {
     traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);

@@ -122,6 +122,8 @@ template <typename R> struct SceneView {
   const uint32_t* linear_rec;  // n_linear leaf records (LIN_DWORDS each) in BVH left-first DFS order
   uint32_t n_linear;           // 0 = scene not eligible for the leaf-list path
   uint32_t linear_has_media;   // some leaf record carries LINF_MEDIUM
+  uint32_t linear_xf_mask, linear_cube_mask, linear_medium_mask;  // bit k = LINF_* of record k (kernel arguments:
+                                                                  // scalar registers, no per-leaf flag read from LDS)
   uint32_t root;
   uint32_t root2;  // root of nodes2 (REF_NONE if the ordered walk is not available)
   uint32_t lights_kind, n_lights;

@@ -363,8 +363,15 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
 #undef UP
   s.view.n_linear = sizeof(R) == 4 ? (uint32_t)linear.size() : 0u;
   s.view.linear_has_media = 0;
-  for (size_t k = 0; k < linear_rec.size() / LIN_DWORDS; ++k)
-    if (linear_rec[k * LIN_DWORDS + LIN_FLAGS] & LINF_MEDIUM) s.view.linear_has_media = 1;
+  s.view.linear_xf_mask = s.view.linear_cube_mask = s.view.linear_medium_mask = 0;
+  static_assert(LIN_MAX_LEAVES <= 32, "leaf-list flag masks are 32 bits wide");
+  for (size_t k = 0; k < linear_rec.size() / LIN_DWORDS; ++k) {
+    const uint32_t f = linear_rec[k * LIN_DWORDS + LIN_FLAGS];
+    if (f & LINF_MEDIUM) s.view.linear_has_media = 1;
+    if (f & LINF_XF) s.view.linear_xf_mask |= 1u << k;
+    if (f & LINF_CUBE) s.view.linear_cube_mask |= 1u << k;
+    if (f & LINF_MEDIUM) s.view.linear_medium_mask |= 1u << k;
+  }
   s.view.root = d.root;
   s.view.root2 = s.ordered_root;
   s.view.lights_kind = d.lights_kind;
