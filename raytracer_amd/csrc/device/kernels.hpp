@@ -62,7 +62,11 @@ template <typename R> RT_DEV R perlin_turb(const uint8_t* tab, Vec3<R> p) {
 }
 
 // ---- texture.rs:33-69 ---------------------------------------------------------------------
-template <typename R>
+// NOISE: whether this instantiation carries the Perlin code (extension).  Only the reference-order kernel has a
+// NOISE = true variant (and the f64 audit kernel): inlined into the fast kernels' bounce loops the noise code
+// costs the common, noise-free path registers (measured: 116 B of scratch, -6 % on the BVH scenes), and as a
+// real call it costs 25-30 % (AMDGPU call ABI).  Scenes with a noise texture are routed to that variant.
+template <typename R, bool NOISE = false>
 RT_DEV Vec3<R> texture_value(const SceneView<R>& sc, uint32_t idx, Vec2<R> uv, Vec3<R> p, Vec3<R> normal) {
   for (;;) {
     Texture<R> t = sc.textures[idx];
@@ -86,7 +90,7 @@ RT_DEV Vec3<R> texture_value(const SceneView<R>& sc, uint32_t idx, Vec2<R> uv, V
       const R color_scale = R(1) / R(255);
       return Vec3<R>((R)px[0] * color_scale, (R)px[1] * color_scale, (R)px[2] * color_scale);
     }
-    if (t.tag == TEX_NOISE) {
+    if (NOISE && t.tag == TEX_NOISE) {
       const R m = R(0.5) * (R(1) + rsin(t.color[0] * p.z + R(10) * perlin_turb(sc.texels + t.texel_offset, p)));
       return Vec3<R>(m, m, m);
     }
@@ -197,9 +201,10 @@ RT_DEV R lights_pdf(const SceneView<R>& sc, const Light<R>* lights, Vec3<R> orig
 }
 
 // texture.value() of a material's texture; Solid textures were folded into the material record
-template <typename R> RT_DEV Vec3<R> material_color(const SceneView<R>& sc, const Material<R>& m, const HitRec<R>& h) {
+template <typename R, bool NOISE = false>
+RT_DEV Vec3<R> material_color(const SceneView<R>& sc, const Material<R>& m, const HitRec<R>& h) {
   if (m.flags & MATF_SOLID) return Vec3<R>(m.color[0], m.color[1], m.color[2]);
-  return texture_value(sc, m.texture, h.uv, h.p, h.normal);
+  return texture_value<R, NOISE>(sc, m.texture, h.uv, h.p, h.normal);
 }
 
 // material.rs:128-133
@@ -215,12 +220,12 @@ template <typename R> RT_DEV R reflectance(R cosine, R ref_idx) {
 // One vertex of ray_color (main.rs:77-102) after the closest hit is known.  Updates the
 // running throughput / radiance, overwrites `ray` with the scattered ray and returns true if
 // the path continues.
-template <typename R, bool STATS>
+template <typename R, bool STATS, bool NOISE = false>
 RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material<R>& m, const HitRec<R>& h,
                   RayT<R>& ray, Vec3<R>& thr, Vec3<R>& L, Rng& rng, Cnt<STATS>& cnt) {
   if (m.tag == MAT_DIFFUSE_LIGHT) {  // scatter -> None: return emitted (main.rs:101)
     cnt.template inc<ST_EMITTER>();
-    if (h.front_face) L = madd(L, thr, material_color(sc, m, h));
+    if (h.front_face) L = madd(L, thr, material_color<R, NOISE>(sc, m, h));
     return false;
   }
   if (m.tag == MAT_DIELECTRIC) {  // material.rs:66-87; emitted is dropped (main.rs:81-83)
@@ -251,7 +256,7 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
   }
   // Lambertian / Isotropic: ScatterRecord::PDF with a cosine PDF (material.rs:59-65, 97-100)
   cnt.template inc<ST_DIFFUSE>();
-  Vec3<R> attenuation = material_color(sc, m, h);
+  Vec3<R> attenuation = material_color<R, NOISE>(sc, m, h);
   const bool have_lights = sc.lights_kind != LIGHTS_NONE;
   // PDF::generate (pdf.rs:33-39): Mixture[light, cosine].choose(), then either
   // Hittable::random (hittable.rs:502-515) or the cosine direction (alias.rs:72-82).  Both
@@ -449,7 +454,7 @@ struct RenderArgs {
 // LaunchShape::trav == 2 launches unless RT_ORDERED_NO_REFILL is set in the environment)
 constexpr int TRAV_REFERENCE = 0, TRAV_LINEAR = 1, TRAV_ORDERED = 2;
 
-template <typename R, bool STATS, bool EARLY_EXIT, int TRAV>
+template <typename R, bool STATS, bool EARLY_EXIT, int TRAV, bool NOISE = false>
 __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : RT_RENDER_MIN_WAVES) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
                                                        R* __restrict__ accum, DeviceStats* stats) {
   constexpr bool LINEAR = TRAV == TRAV_LINEAR;
@@ -560,7 +565,7 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : RT_RE
         L = madd(L, thr, h.normal);
         cont = false;
 #else
-        cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
+        cont = shade<R, STATS, NOISE>(sc, lights, mat, h, ray, thr, L, rng, cnt);
 #endif
       }
       RT_STAMP(5);

@@ -122,6 +122,7 @@ template <typename R> struct SceneView {
   const uint32_t* linear_rec;  // n_linear leaf records (LIN_DWORDS each) in BVH left-first DFS order
   uint32_t n_linear;           // 0 = scene not eligible for the leaf-list path
   uint32_t linear_has_media;   // some leaf record carries LINF_MEDIUM
+  uint32_t has_noise;          // some texture is TEX_NOISE (extension): only the reference-order kernel evaluates it
   uint32_t linear_xf_mask, linear_cube_mask, linear_medium_mask;  // bit k = LINF_* of record k (kernel arguments:
                                                                   // scalar registers, no per-leaf flag read from LDS)
   uint32_t root;

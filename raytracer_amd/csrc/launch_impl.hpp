@@ -77,12 +77,27 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
     return hipGetLastError();
   }
 #endif
-  if (stats)
-    hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
-                       accum, dstats);
-  else
-    hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
-                       accum, dstats);
+  // The reference-order kernel is the one that carries the Perlin texture code (extension): always in the f64
+  // audit build, and as a separate instantiation in f32, launched only for scenes that have a noise texture
+  // (rt_api.hip routes those here) so that no other kernel pays registers for it.
+  constexpr bool F64 = sizeof(RT_REAL) == 8;
+  if (F64 || sc.has_noise) {
+    if (stats)
+      hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE, true>), grid, block, lds, st, sc,
+                         cam, a, accum, dstats);
+    else
+      hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_REFERENCE, true>), grid, block, lds, st, sc,
+                         cam, a, accum, dstats);
+    return hipGetLastError();
+  }
+  if constexpr (!F64) {
+    if (stats)
+      hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
+                         accum, dstats);
+    else
+      hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
+                         accum, dstats);
+  }
   return hipGetLastError();
 }
 

@@ -362,6 +362,9 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
   UP(linear_rec, linear_rec)
 #undef UP
   s.view.n_linear = sizeof(R) == 4 ? (uint32_t)linear.size() : 0u;
+  s.view.has_noise = 0;
+  for (uint32_t i = 0; i < d.n_textures; ++i)
+    if (d.tex_tag[i] == RT_TEX_NOISE) s.view.has_noise = 1;
   s.view.linear_has_media = 0;
   s.view.linear_xf_mask = s.view.linear_cube_mask = s.view.linear_medium_mask = 0;
   static_assert(LIN_MAX_LEAVES <= 32, "leaf-list flag masks are 32 bits wide");
@@ -745,7 +748,8 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
                        const rt_camera* cam = nullptr, uint32_t max_depth = 0) {
   LaunchShape sh;
   sh.trav = 0;  // the reference's left-first walk: always valid
-  if (f32_fast && s->boxes_conservative && cam && cam->time_open >= s->safe_t_lo && cam->time_close <= s->safe_t_hi)
+  // (a scene with a Perlin texture, an extension, renders on the reference-order kernel: see launch_impl.hpp)
+  if (f32_fast && !s->f32.view.has_noise && s->boxes_conservative && cam && cam->time_open >= s->safe_t_lo && cam->time_close <= s->safe_t_hi)
     sh.trav = s->f32.view.n_linear > 0 ? 1 : (s->f32.ordered_root != RT_REF_NONE ? 2 : 0);
   uint32_t tx = (w + 15) / 16, ty = (h + 15) / 16;
   sh.tiles = tx * ty;
