@@ -71,8 +71,6 @@ RT_DEV Vec3<R> texture_value(const SceneView<R>& sc, uint32_t idx, Vec2<R> uv, V
   for (;;) {
     Texture<R> t = sc.textures[idx];
     if (t.tag == TEX_CHECKER) {
-      const R scale = R(10);
-      (void)scale;
       R sines = sin_scaled10(p.x) * sin_scaled10(p.y) * sin_scaled10(p.z);
       idx = sines < R(0) ? t.odd : t.even;
       continue;
@@ -117,26 +115,8 @@ template <typename R> RT_DEV Vec3<R> random_in_unit_disk(Rng& rng) {
     if (sqrlen(p) < R(1)) return p;
   }
 }
-template <typename R> RT_DEV Vec3<R> random_cosine_direction(Rng& rng) {
-  R r1 = rng.next<R>();
-  R r2 = rng.next<R>();
-  R z = rroot(R(1) - r2);
-  R sn, cs;
-  sincos_2pi(r1, sn, cs);
-  R x = cs * rroot(r2);
-  R y = sn * rroot(r2);
-  return Vec3<R>(x, y, z);
-}
-template <typename R> RT_DEV Vec3<R> random_to_sphere(Rng& rng, R radius, R distance_squared) {
-  R r1 = rng.next<R>();
-  R r2 = rng.next<R>();
-  R z = R(1) + r2 * (rroot(R(1) - rdiv(radius * radius, distance_squared)) - R(1));
-  R sn, cs;
-  sincos_2pi(r1, sn, cs);
-  R x = cs * rroot(R(1) - z * z);
-  R y = sn * rroot(R(1) - z * z);
-  return Vec3<R>(x, y, z);
-}
+// random_cosine_direction (alias.rs:72-82) and random_to_sphere (alias.rs:84-94) live inside shade(): the two
+// share one "draw r1 r2, map (z, radial) into an ONB" code path there.
 
 // ---- hittable.rs:477-500 on the flattened light list (random(): see shade()) -------------------
 template <typename R, bool STATS>
@@ -561,12 +541,7 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : RT_RE
           mat = sc.materials[h.material];
         }
         RT_STAMP(4);
-#ifdef RT_ABL_NOSHADE
-        L = madd(L, thr, h.normal);
-        cont = false;
-#else
         cont = shade<R, STATS, NOISE>(sc, lights, mat, h, ray, thr, L, rng, cnt);
-#endif
       }
       RT_STAMP(5);
       ++slot;
