@@ -1097,7 +1097,7 @@ static int kat_common(int device, size_t in_bytes[], const void* in[], int n_in,
 
 struct KatCtx {
   uint32_t n;
-  int use_f32;
+  int variant;  // sphere_uv / rotate: use the f32 kernels; philox: 1 = the path streams' generator (7 rounds)
 };
 
 int rt_kat_sphere_uv(int device, uint32_t n, const double* p, double* uv, int use_f32) {
@@ -1108,7 +1108,7 @@ int rt_kat_sphere_uv(int device, uint32_t n, const double* p, double* uv, int us
   return kat_common(device, ib, in, 1, n * 2 * sizeof(double), uv,
                     [](void** di, void* dout, void* ctx) -> hipError_t {
                       auto* k = (KatCtx*)ctx;
-                      return k->use_f32 ? launch_kat_sphere_uv_f32(k->n, (const double*)di[0], (double*)dout, nullptr)
+                      return k->variant ? launch_kat_sphere_uv_f32(k->n, (const double*)di[0], (double*)dout, nullptr)
                                         : launch_kat_sphere_uv_f64(k->n, (const double*)di[0], (double*)dout, nullptr);
                     },
                     &c);
@@ -1123,7 +1123,7 @@ int rt_kat_rotate(int device, uint32_t n, const double* angle, const double* axi
   return kat_common(device, ib, in, 3, n * 3 * sizeof(double), out,
                     [](void** di, void* dout, void* ctx) -> hipError_t {
                       auto* k = (KatCtx*)ctx;
-                      return k->use_f32 ? launch_kat_rotate_f32(k->n, (const double*)di[0], (const double*)di[1],
+                      return k->variant ? launch_kat_rotate_f32(k->n, (const double*)di[0], (const double*)di[1],
                                                                 (const double*)di[2], (double*)dout, nullptr)
                                         : launch_kat_rotate_f64(k->n, (const double*)di[0], (const double*)di[1],
                                                                 (const double*)di[2], (double*)dout, nullptr);
@@ -1141,7 +1141,7 @@ int rt_kat_philox(int device, uint32_t n, const uint32_t* ctr, const uint32_t* k
   return kat_common(device, ib, in, 2, n * 4 * sizeof(uint32_t), out,
                     [](void** di, void* dout, void* ctx) -> hipError_t {
                       auto* k = (KatCtx*)ctx;
-                      return launch_kat_philox(k->n, (const uint32_t*)di[0], (const uint32_t*)di[1], k->use_f32,
+                      return launch_kat_philox(k->n, (const uint32_t*)di[0], (const uint32_t*)di[1], k->variant,
                                                (uint32_t*)dout, nullptr);
                     },
                     &c);
