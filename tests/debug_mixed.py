@@ -1,3 +1,4 @@
+"""Debug helper for tests/test_mixed_scenes.py (uses the oracle, so it lives under tests/; not collected by pytest):\nf64 audit kernel vs oracle on one generated scene, per depth, listing the primary objects of deviating pixels.\nusage: python tests/debug_mixed.py <seed> <n>"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, raytracer_amd as R, oracle_ffi as O
@@ -7,7 +8,7 @@ hs = R.HostScene(9, A, n=n, scene_seed=seed); ds = R.DeviceScene(hs, 0); os_ = O
 h = R.image_height(W, A)
 oid, ot, on, ouv, off = os_.primary_hits(W, h, seed=3, time=0.0)
 draws = O.scene_draws(seed, 0, 12 * n)
-shape = (draws[0::12] * 9).astype(int); mat = (draws[1::12] * 7).astype(int)
+shape = (draws[0::12] * 14).astype(int); mat = (draws[1::12] * 9).astype(int)
 names = {0: "ground"}
 for i in range(n): names[i + 1] = f"obj{i} shape{shape[i]} mat{mat[i]}"
 for d in (1, 2, 3, 12):

@@ -1,5 +1,6 @@
 """Wide sweep of generated scenes (mixed_scene) through every parity level; prints only deviations.
-usage: python tools/sweep_mixed.py <first_seed> <last_seed>   (on the GPU box)"""
+Not collected by pytest (it uses the oracle, so it lives under tests/).
+usage: python tests/sweep_mixed.py <first_seed> <last_seed>   (on the GPU box)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
