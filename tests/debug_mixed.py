@@ -1,4 +1,6 @@
-"""Debug helper for tests/test_mixed_scenes.py (uses the oracle, so it lives under tests/; not collected by pytest):\nf64 audit kernel vs oracle on one generated scene, per depth, listing the primary objects of deviating pixels.\nusage: python tests/debug_mixed.py <seed> <n>"""
+"""Debug helper for tests/test_mixed_scenes.py (uses the oracle, so it lives under tests/; not collected by pytest):
+f64 audit kernel vs oracle on one generated scene, per depth, listing the primary objects of deviating pixels.
+usage: python tests/debug_mixed.py <seed> <n>"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, raytracer_amd as R, oracle_ffi as O
