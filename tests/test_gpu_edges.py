@@ -260,3 +260,31 @@ def test_scenes_come_and_go_without_leaking_device_memory():
     ia2, _ = a.render(40, 40, 4, 5, seed=1)
     np.testing.assert_allclose(ia, ia2, rtol=1e-5, atol=1e-6)
     assert ib.shape == (26, 40, 3)
+
+
+@pytest.mark.parametrize("size", [(2, 2), (37, 23), (3, 130)])
+def test_empty_world_and_ragged_tiny_images(size):
+    """Hittable::Empty as the whole world (new_bvh of no objects, hittable.rs:171, 413): every ray misses, every
+    sample is the background (main.rs:104) — through every kernel family, on image sizes that fill no tile."""
+    import types
+    import ctypes as C
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    w, h = size
+    d = F.RtSceneDesc()
+    d.abi_version = F.RT_ABI_VERSION
+    d.root = 0xFFFFFFFF
+    d.lights_kind = 0
+    bg = (0.5, 0.7, 1.0)
+    for k in range(3):
+        d.background[k] = bg[k]
+    view = R.HostScene(5, w / h)  # only for its camera (kept alive: the camera lives inside the host scene)
+    ds = R.DeviceScene(types.SimpleNamespace(desc=d, camera=view.camera), 0)
+    for kw in ({}, {"f64": True}, {"force_bvh": True}):
+        a, st = ds.render(w, h, 5, 7, seed=3, stats=True, **kw)
+        assert a.shape == (h, w, 3)
+        np.testing.assert_allclose(a, np.broadcast_to(np.array(bg) * 5, a.shape), rtol=1e-6)
+        assert st["rays"] == w * h * 5 and st["misses"] == w * h * 5 and st["closest_hits"] == 0
+    for kw in ({}, {"f64": True}, {"fast": True}):
+        ids = ds.primary_hits(w, h, **kw)[0]
+        assert (ids == 0xFFFFFFFF).all()
