@@ -78,7 +78,10 @@ class HostScene:
         F.check_host(F.host.rth_scene_build(C.byref(o), C.byref(h)))
         self._h = h
         self.desc = F.host.rth_scene_desc(h).contents
-        self.camera = F.host.rth_scene_camera(h).contents
+        # a COPY: the camera is plain data, and a reference into the host scene would dangle in
+        # `HostScene(...).camera` once the temporary is collected (desc, below, points into the scene's arrays
+        # and is only valid while this object lives)
+        self.camera = F.RtCamera.from_buffer_copy(F.host.rth_scene_camera(h).contents)
         self.n_objects = int(F.host.rth_scene_object_count(h))
         self.bvh_calls = int(F.host.rth_scene_bvh_calls(h))
         self.scene_id = scene_id
