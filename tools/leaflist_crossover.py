@@ -1,5 +1,6 @@
 """Leaf list vs ordered walk on scenes of 13-33 leaves (bvh_stress with a handful of spheres).
-Run with the default build (LIN_MAX_LEAVES 16: ordered walk) and with a LIN_MAX_LEAVES=32 variant."""
+Compare the default build (RT_LIN_MAX_LEAVES 32: leaf list) with `tools/build_variant.sh lin16 -DRT_LIN_MAX_LEAVES=16`
+(ordered BVH walk above 16 leaves): measured +21 % at 21 leaves, +4 % at 27, +9 % at 32 for the leaf list."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as R

@@ -1,3 +1,5 @@
+"""Scene-size sweep of bvh_stress: host build time, device upload time and render time per sphere count.
+usage: python tools/scale_probe.py <n> [<n> ...]   (appends to gpurun_out/scale_probe.log)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as R
