@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, raytracer_amd as R
 for name, sid, asp, n, depth in (("random_scene", 0, 16 / 9, 0, 50), ("final_scene", 8, 1.0, 0, 50), ("bvh_stress_20k", 7, 16 / 9, 20000, 50),
-                                 ("cornell_box", 6, 1.0, 0, 50), ("small_scene", 5, 1.5, 0, 5), ("cube_scene", 4, 1.5, 0, 5), ("mixed 3/70", 9, 1.5, 70, 12)):
+                                 ("bvh_stress_1M", 7, 16 / 9, 1000000, 50), ("cornell_box", 6, 1.0, 0, 50), ("small_scene", 5, 1.5, 0, 5), ("cube_scene", 4, 1.5, 0, 5), ("mixed 3/70", 9, 1.5, 70, 12)):
     hs = R.HostScene(sid, asp, n=n, scene_seed=3 if sid == 9 else 5, texels=R.load_earthmap() if sid in (2, 4, 8) else None)
     ds = R.DeviceScene(hs, 0)
     h = R.image_height(128, asp)
