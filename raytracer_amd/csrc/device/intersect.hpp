@@ -89,6 +89,10 @@ struct SphereRoots {
 // Both roots at once: a constant medium probes its boundary twice with different windows
 // (hittable.rs:324-331); the quadratic is solved once and each probe only picks its root.
 RT_DEV SphereRoots sphere_roots(Vec3<float> o, Vec3<float> d, float a, Vec3<float> c, float radius) {
+  // Keep the f32 -> f64 conversions of the ray HERE (an empty asm the optimiser cannot see through): hoisted out
+  // of the leaf-list loop they occupy 12 vector registers for the whole walk, which costs the persistent kernel
+  // its sixth wave per SIMD (measured: 60.4 -> 65.3 Grays/s on Cornell with the barrier and 6 waves).
+  asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(d.x), "+v"(d.y), "+v"(d.z));
   const double ocx = (double)o.x - (double)c.x, ocy = (double)o.y - (double)c.y, ocz = (double)o.z - (double)c.z;
   const double dx = d.x, dy = d.y, dz = d.z;
   // explicit FMAs: one fixed form at every inlined copy (see mul_add3)

@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
 // (pixel, sample), not by who renders it.
 constexpr uint32_t UNIT_RING = 32;
 #ifndef RT_PERSIST_MIN_WAVES
-#define RT_PERSIST_MIN_WAVES 5  // measured: 5 (no spills) 54.9, 6 (a few spills) 54.3, 7: 41.2 Grays/s
+#define RT_PERSIST_MIN_WAVES 6  // measured (after sphere_roots stopped the f64 hoist): 4: 54.2, 5: 61.1, 6 (80 VGPRs, 32 B scratch): 65.3, 7: 63.1 Grays/s
 #endif
 template <bool STATS>
 __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_kernel(SceneView<float> sc, CameraView<float> cam,
