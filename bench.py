@@ -186,14 +186,14 @@ def main():
         # issue rate is the roof; a scene larger than that is priced against HBM.
         d = hs.desc
         scene_bytes = 32 * d.n_nodes + 16 * d.n_spheres + 48 * d.n_mspheres + 32 * d.n_cubes + 128 * d.n_complex
-        # measured once with PMC counters for the default workload (profiles/r01i_traffic.txt); null otherwise
+        # measured once with PMC counters for the default workload (profiles/r01j_traffic.txt); null otherwise
         default_workload = (args.scene == "cornell_box" and width == 1024 and args.spp == 4096 and launches == args.steps)
         traffic = 3.2e9 if default_workload else None
         if scene_bytes <= 4 << 20:
             out["roofline"] = {"bound": "valu_fp32", "achieved": tflops, "peak": PEAK_FP32_VALU_TFLOPS,
                                "unit": "TFLOP/s", "frac": valu_frac, "traffic": traffic,
                                "traffic_note": "bytes per launch at the L2<->fabric boundary (upper bound: 5.03e7 float-atomic "
-                                               "requests x 64 B + 4.5 MB reads; profiles/r01i_traffic.txt); the algorithmic "
+                                               "requests x 64 B + 4.5 MB reads; profiles/r01j_traffic.txt); the algorithmic "
                                                "bytes are served from LDS" if traffic else None}
         else:
             out["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
