@@ -755,10 +755,10 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   sh.tiles = tx * ty;
   sh.stack_depth = sh.trav == 2 ? std::max(s->f32.ordered_height, 1u) : s->stack_depth;
   // ordered walk: the longer a scene's walks, the smaller the idle fraction worth interrupting them for
-  // (measured optimum: 5/8 at ~500-1500 nodes, 4/8 at 20 k, 3/8 at 1 M)
+  // (measured optimum, re-tuned on the final kernels: 6/8 at ~500-1500 nodes, 4/8 at 20 k, 3/8 at 1 M)
   static const char* re = getenv("RT_REFILL_EIGHTHS");  // tuning override
   const uint32_t n_nodes = s->n_nodes;
-  sh.refill_eighths = re ? (uint32_t)std::min(8, std::max(1, atoi(re))) : n_nodes <= 4096 ? 5u : n_nodes <= 65536 ? 4u : 3u;
+  sh.refill_eighths = re ? (uint32_t)std::min(8, std::max(1, atoi(re))) : n_nodes <= 4096 ? 6u : n_nodes <= 65536 ? 4u : 3u;
   uint32_t waves = sh.tiles * 4;
   static const char* tw = getenv("RT_TARGET_WAVES");  // tuning override
   const uint32_t target = tw ? (uint32_t)std::max(1, atoi(tw)) : TARGET_WAVES;
