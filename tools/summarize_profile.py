@@ -28,10 +28,14 @@ if stats:
 trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
 if trace:
     rows = list(csv.DictReader(open(trace[0])))
-    rk = [r for r in rows if "render_kernel" in r["Kernel_Name"]]
-    if rk:
-        r = rk[0]
-        lines += ["## render_kernel dispatch resources (kernel trace)", ""]
+    seen = set()
+    for r in rows:  # one entry per render kernel (first dispatch of each)
+        kn = r["Kernel_Name"].split("(")[0].replace("void rt::", "")
+        if "render" not in kn or kn in seen:
+            continue
+        seen.add(kn)
+        lines += [f"## `{kn}` dispatch resources (kernel trace; VGPR_Count as rocprofv3 reports it, half the compiler's "
+                  f"per-lane count for these wave64 kernels: 40 = 80 VGPRs)", ""]
         for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size",
                   "Grid_Size"):
             if k in r:
