@@ -49,7 +49,8 @@ typedef struct rth_render_opts {   /* = struct Opts, main.rs:28-49, plus what ma
   uint32_t image_width;            /* -i, default 1200 */
   uint32_t samples_per_pixel;      /* --samples-per-pixel, default 500 */
   uint32_t max_depth;              /* --max-depth, default 5 */
-  int32_t device;
+  int32_t device;                  /* GPU index; negative = every GPU of the node (rt_render_multi), as rayon
+                                      takes every core (main.rs:157) */
   uint64_t seed;
 } rth_render_opts;
 

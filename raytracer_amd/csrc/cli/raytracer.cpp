@@ -48,7 +48,7 @@ const char* USAGE =
     "        --samples-per-pixel <samples-per-pixel>    [default: 500]\n"
     "    -s, --scene <scene>                            [default: 3]\n"
     "\nEXTENSIONS (not in the reference):\n"
-    "        --device <n>          GPU to render on [default: 0]\n"
+    "        --device <n|all>      GPU to render on, or every GPU of the node (samples sharded) [default: 0]\n"
     "        --seed <n>            Philox key of the per-path draws [default: 1]\n"
     "        --scene-seed <n>      scene generator seed (scenes.rs:64 uses 5) [default: 5]\n"
     "        --bvh-seed <n>        BVH split-axis stream [default: 7]\n"
@@ -172,9 +172,13 @@ int main(int argc, char** argv) {
     } else if (name == "--max-depth") {
       u32(o.max_depth);
     } else if (name == "--device") {
-      uint32_t d = 0;
-      u32(d);
-      o.device = (int)d;
+      if (need() == "all") {
+        o.device = -1;
+      } else {
+        uint32_t d = 0;
+        u32(d);
+        o.device = (int)d;
+      }
     } else if (name == "--seed") {
       u64(o.seed);
     } else if (name == "--scene-seed") {

@@ -1,5 +1,7 @@
 // C ABI of librt_host.so (include/rt_host.h).
+#include <algorithm>
 #include <cstring>
+#include <vector>
 #include <stdexcept>
 #include <string>
 
@@ -97,13 +99,6 @@ int rth_render(const rth_render_opts* o, uint8_t* rgb8, float* accum, uint32_t* 
   rth_scene* hs = nullptr;
   int rc = rth_scene_build(&o->scene, &hs);
   if (rc != RT_OK) return rc;
-  rt_scene* ds = nullptr;
-  rc = rt_scene_create(o->device, &hs->desc, &ds);
-  if (rc != RT_OK) {
-    g_err = std::string("rth_render: ") + rt_last_error();
-    rth_scene_free(hs);
-    return rc;
-  }
   rt_params p;
   std::memset(&p, 0, sizeof(p));
   p.width = w;
@@ -117,12 +112,41 @@ int rth_render(const rth_render_opts* o, uint8_t* rgb8, float* accum, uint32_t* 
     local.resize((size_t)w * h * 3);
     acc = local.data();
   }
-  rc = rt_render(ds, &hs->camera, &p, acc, stats);
+  if (o->device < 0) {
+    // every GPU of the node, as rayon takes every core (main.rs:157): the samples are sharded by rt_render_multi;
+    // *stats receives the sum of the shards' counters and the LONGEST shard's kernel time
+    const int n_dev = rt_device_count();
+    if (n_dev <= 0) {
+      rth_scene_free(hs);
+      return fail(RT_ERR_HIP, "rth_render: no GPU found");
+    }
+    std::vector<int> devices((size_t)n_dev);
+    for (int g = 0; g < n_dev; ++g) devices[(size_t)g] = g;
+    std::vector<rt_stats> per((size_t)n_dev);
+    rc = rt_render_multi(n_dev, devices.data(), &hs->desc, &hs->camera, &p, acc, per.data());
+    if (rc == RT_OK && stats) {
+      std::memset(stats, 0, sizeof(*stats));
+      for (const rt_stats& s : per) {
+        stats->rays += s.rays;
+        stats->light_probes += s.light_probes;
+        stats->medium_probes += s.medium_probes;
+        stats->nonfinite_samples += s.nonfinite_samples;
+        stats->launches += s.launches;
+        stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms);
+      }
+    }
+  } else {
+    rt_scene* ds = nullptr;
+    rc = rt_scene_create(o->device, &hs->desc, &ds);
+    if (rc == RT_OK) {
+      rc = rt_render(ds, &hs->camera, &p, acc, stats);
+      rt_scene_destroy(ds);
+    }
+  }
   if (rc != RT_OK)
     g_err = std::string("rth_render: ") + rt_last_error();
   else
     rt_tonemap(acc, (uint64_t)w * h, p.spp, rgb8);
-  rt_scene_destroy(ds);
   rth_scene_free(hs);
   return rc;
 }

@@ -85,3 +85,18 @@ def test_cli_missing_texture_and_missing_directory(tmp_path):
     assert p.returncode == 1 and "earth texture" in p.stderr
     p = run("-s", "5", "-i", "32", "--samples-per-pixel", "1", cwd=str(tmp_path))  # no renders/ directory
     assert p.returncode == 1 and "cannot write" in p.stderr and "Created image!" not in p.stdout
+
+
+@pytest.mark.gpu
+def test_cli_device_all_equals_device_0_on_a_one_gpu_box(tmp_path):
+    """--device all shards the samples over every GPU of the node (rt_render_multi); with one GPU that is the
+    same render (same Philox streams), reduced through the multi-device path."""
+    os.makedirs(tmp_path / "renders")
+    imgs = []
+    for dev in ("0", "all"):
+        p = run("-s", "6", "-i", "80", "-a", "1", "--samples-per-pixel", "32", "--max-depth", "20", "--device", dev,
+                "-o", f"renders/{dev}.png", cwd=str(tmp_path))
+        assert p.returncode == 0, p.stderr
+        with Image.open(tmp_path / "renders" / f"{dev}.png") as im:
+            imgs.append(np.asarray(im).astype(np.int32))
+    assert np.abs(imgs[0] - imgs[1]).max() <= 1 and (imgs[0] != imgs[1]).mean() < 0.01
