@@ -121,3 +121,22 @@ def test_tonemap_matches_reference_formula():
     g = np.sqrt(vals[:7])
     assert list(got.reshape(-1)[:7]) == [int(min(max(x, 0), 0.9999) * 256) for x in g]
     assert list(got.reshape(-1)[7:10]) == [0, 0, 255]
+
+
+def test_no_gpu_means_an_error_not_a_cpu_fallback():
+    """The product path has no CPU fallback: on a machine without a GPU (the build container) a valid scene
+    is refused with RT_ERR_HIP and a message, and the command line exits 1.  Skipped where a GPU exists."""
+    import subprocess
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    if F.hip.rt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    hs = R.HostScene("cornell_box", 1.0)
+    out = C.c_void_p()
+    rc = F.hip.rt_scene_create(0, C.byref(hs.desc), C.byref(out))
+    assert rc == F.RT_ERR_HIP and F.hip.rt_last_error().decode()
+    with pytest.raises(F.RtError):
+        R.render(scene=5, image_width=16, samples_per_pixel=1)
+    p = subprocess.run([R.CLI, "-s", "5", "-i", "16", "--samples-per-pixel", "1", "-o", "/tmp/never.png"],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1 and p.stderr.startswith("error:") and "Created image!" not in p.stdout
