@@ -15,11 +15,16 @@
 namespace rt {
 
 constexpr int BLOCK = 256;
+// waves per SIMD the register allocator must leave room for (measured on MI355X):
+// reference-order f32 kernel: 4: 25.0, 5: 28.0, 6: 29.4, 7: 26.6, 8: 20.9 Grays/s on simple_light (the reference's
+// default scene), 6 is also +25..37 % over 4 on the forced reference walk of the BVH scenes; the f64 audit
+// kernels stay at 4; the leaf-list kernel gains at 6; the refill kernel is best at 5 (spills at 6)
 #ifndef RT_RENDER_MIN_WAVES
-#define RT_RENDER_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
+#define RT_RENDER_MIN_WAVES 6
 #endif
-// measured on MI355X: the leaf-list kernel (91 VGPRs at 4) gains 4 % at 6 waves, the refill kernel 3-5 % at 5
-// and loses at 6 (spills); the reference-order and f64 kernels stay at 4
+#ifndef RT_RENDER_F64_MIN_WAVES
+#define RT_RENDER_F64_MIN_WAVES 4
+#endif
 #ifndef RT_LINEAR_MIN_WAVES
 #define RT_LINEAR_MIN_WAVES 6
 #endif
@@ -435,7 +440,7 @@ struct RenderArgs {
 constexpr int TRAV_REFERENCE = 0, TRAV_LINEAR = 1, TRAV_ORDERED = 2;
 
 template <typename R, bool STATS, bool EARLY_EXIT, int TRAV, bool NOISE = false>
-__global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : RT_RENDER_MIN_WAVES) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
+__global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : (sizeof(R) == 8 ? RT_RENDER_F64_MIN_WAVES : RT_RENDER_MIN_WAVES)) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
                                                        R* __restrict__ accum, DeviceStats* stats) {
   constexpr bool LINEAR = TRAV == TRAV_LINEAR;
   extern __shared__ uint32_t lds_stack[];
