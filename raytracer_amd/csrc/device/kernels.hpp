@@ -430,7 +430,7 @@ struct RenderArgs {
   uint32_t refill_eighths;  // render_refill_kernel: refill when this many eighths of the unfinished lanes idle (1..8)
   uint32_t unit_samples;    // render_persist_kernel: samples per (8x8 tile, sample range) unit
   uint32_t wave_tiles_x, wave_tiles, total_units;
-  uint32_t pad;
+  uint32_t leaf_shift;  // refill kernel: run the leaf tests once (walking lanes >> leaf_shift) lanes wait at a leaf
   uint64_t seed;
 };
 
@@ -599,9 +599,6 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : (size
 // record, Material::scatter, next ray or next camera sample) and re-enters the loop with them
 // refilled — the lanes still walking keep their state in registers and their stack in LDS.  Same
 // paths, same draws as render_kernel: a lane's vertices are still processed in order.
-#ifndef RT_LEAF_SHIFT
-#define RT_LEAF_SHIFT 2  // run the leaf tests once (walking lanes >> RT_LEAF_SHIFT) lanes wait at a leaf
-#endif
 template <bool STATS>
 __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kernel(SceneView<float> sc, CameraView<float> cam,
                                                                                  RenderArgs a, float* __restrict__ accum,
@@ -684,7 +681,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
     for (;;) {
       const uint32_t n_walking = (uint32_t)__popcll(__ballot(walking));
       if (n_walking + refill_at <= n_unfinished) break;
-      const uint32_t leaves_at = (n_walking >> RT_LEAF_SHIFT) > 0 ? (n_walking >> RT_LEAF_SHIFT) : 1u;
+      const uint32_t leaves_at = (n_walking >> a.leaf_shift) > 0 ? (n_walking >> a.leaf_shift) : 1u;
       RT_STAMP(2);
       for (;;) {
         const bool at_node = walking && !(walk.cur & REF_LEAF);

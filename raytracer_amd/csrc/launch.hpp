@@ -15,6 +15,7 @@ struct LaunchShape {
   uint32_t splits;       // sample splits along grid.y (atomic accumulation when > 1)
   uint32_t stack_depth;  // LDS traversal-stack entries per lane
   uint32_t refill_eighths = 2;  // ordered walk: see RenderArgs::refill_eighths
+  uint32_t leaf_shift = 2;      // ordered walk: see RenderArgs::leaf_shift
   // leaf-list scenes, persistent kernel (render_persist_kernel): 0 = off
   uint32_t unit_samples = 0, wave_tiles_x = 0, wave_tiles = 0, total_units = 0;
   int trav;              // 0 reference-order BVH walk, 1 leaf list, 2 ordered BVH walk (f32 only for 1, 2)

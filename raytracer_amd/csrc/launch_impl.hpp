@@ -31,7 +31,7 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   a.wave_tiles_x = shape.wave_tiles_x;
   a.wave_tiles = shape.wave_tiles;
   a.total_units = shape.total_units;
-  a.pad = 0;
+  a.leaf_shift = shape.leaf_shift;
 #if RT_HAS_LINEAR
   if (shape.trav == TRAV_LINEAR && shape.unit_samples > 0) {  // persistent form: grid = workers, not tiles
     if (stats)
