@@ -805,7 +805,6 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
   bool have_pixel = false, lane_done = false, alive = false;
   RayT<R> ray;
   Vec3<R> thr, L;
-  uint32_t depth_left = 0, slot = 0;
   Rng rng;
   rng.init(a.seed, 0, 0);
 #ifdef RT_STAMPS
@@ -859,8 +858,11 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
           const uint32_t xy = s_unit_xy[wave][ui % UNIT_RING], k = s_unit_k[wave][ui % UNIT_RING];
           px = (xy & 0xFFFFu) + (lane & 7u);
           py = (xy >> 16) + (lane >> 3);
+          // s, s_end: GLOBAL sample indices (what the Philox counter takes), so that the sample in flight and the
+          // loop counter are one register
           s = k * a.unit_samples;
-          s_end = s + a.unit_samples < a.n_samples ? s + a.unit_samples : a.n_samples;
+          s_end = a.sample_begin + (s + a.unit_samples < a.n_samples ? s + a.unit_samples : a.n_samples);
+          s += a.sample_begin;
           have_pixel = px < a.width && py < a.height;
           if (!have_pixel) s = s_end;  // a tile that straddles the image edge: nothing to do for this lane
           rng.pixel = py * a.width + px;
@@ -875,8 +877,7 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
         if (lane_done) break;
         continue;
       }
-      rng.sample = a.sample_begin + s;
-      ++s;
+      rng.sample = s;  // ++s when the path ends
       rng.begin(0);
       R ju = rng.next<R>();
       R jv = rng.next<R>();
@@ -885,12 +886,10 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
       ray = camera_ray(cam, u, v, rng);
       thr = Vec3<R>(1, 1, 1);
       L = Vec3<R>(0, 0, 0);
-      depth_left = a.max_depth;
-      slot = 1;
       alive = true;
     }
     RT_STAMP(2);  // camera ray
-    rng.begin(slot);
+    rng.begin(rng.slot + 1u);  // slot 0 = camera, slot b = the b-th ray of the path (also its depth counter)
     cnt.template inc<ST_RAYS>();
     RT_STAMP(3);  // bounce Philox block
     R t;
@@ -914,9 +913,7 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
       cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
     }
     RT_STAMP(6);  // shade (or miss)
-    ++slot;
-    --depth_left;
-    if (depth_left == 0 && cont) {  // the next ray_color call would return 0
+    if (rng.slot == a.max_depth && cont) {  // the next ray_color call would return 0
       depth_exhausted(L, thr);
       cont = false;
     }
@@ -926,6 +923,7 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
       if (!fin) ++nonfinite;
       if (fin) acc = acc + L;
       alive = false;
+      ++s;
     }
   }
 #ifdef RT_STAMPS
