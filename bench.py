@@ -8,11 +8,19 @@ A step = one full pass of the hot path over the workload: every rank renders `sp
 pixel of the Cornell box into an HBM-resident accumulator (rt_render_device), then (N > 1) one RCCL
 sum all-reduce merges the accumulators, then the image is tonemapped on the device.  Weak scaling:
 per-GPU work is fixed (4096 spp per GPU), the merged image has N x 4096 spp.
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  At N = 1 the line also carries
+  * `f64_leg`: the same workload on the f64 audit kernel (rt_render_f64_device) at a stated, smaller spp —
+    the reference computes in f64 (alias.rs:4-7), this is the precision-matched throughput;
+  * `cpu_baseline`: the CPU oracle timed on this box's host cores on a bounded sample of the workload;
+  * `other_configs`: one-GPU lines for BASELINE.json configs C1 / C3 / C4 at bounded spp.
+`--gpus N` with N > 1 from a bare shell (no WORLD_SIZE) starts the N ranks itself, before any GPU call.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,7 +35,9 @@ COST = {
     "flops_per_diffuse_vertex": 60, "flops_per_specular_vertex": 40,
 }
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: vector FP32 peak (= FP32 MFMA peak)
+PEAK_FP64_VALU_TFLOPS = 78.6    # vector FP64: half the FP32 rate
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+METRIC = "Mrays/s (whole node) 1/2/4/8 MI355X, Cornell box 1024² 4096spp"
 
 
 def algorithmic_per_ray(st, n_pixels, launches):
@@ -46,6 +56,208 @@ def algorithmic_per_ray(st, n_pixels, launches):
     return flops / rays, byts / rays
 
 
+def measured_traffic(workload_key):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary
+    (profiles/*_traffic.json, written by tools/pmc_traffic.sh from separate --pmc passes; corrections per
+    MI355X_MICROARCH.md section HBM).  None when no summary covers this workload: never a pasted constant."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("workload") == workload_key:
+            best = (rec, os.path.relpath(path, ROOT))
+    return best
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` from a bare shell: start N fresh rank processes (torch.distributed.run) BEFORE this
+    process has touched a GPU, relay rank 0's JSON line and the children's exit status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line:
+        print(line, flush=True)
+    return rc if rc else (0 if line else 1)
+
+
+class Workload:
+    """One scene resident on one GPU plus its output buffers."""
+
+    def __init__(self, R, torch, scene, width, aspect, n, device):
+        self.R, self.torch = R, torch
+        self.scene, self.width, self.aspect, self.n = scene, width, aspect, n
+        self.height = R.image_height(width, aspect)
+        self.hs = R.HostScene(scene, aspect, n=n)
+        self.ds = R.DeviceScene(self.hs, device)
+        self.device = device
+        dev = torch.device("cuda", device)
+        self.accum = torch.zeros((self.height, width, 3), dtype=torch.float32, device=dev)
+        self.rgb8 = torch.zeros((self.height, width, 3), dtype=torch.uint8, device=dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def scene_bytes(self):
+        d = self.hs.desc
+        return 32 * d.n_nodes + 16 * d.n_spheres + 48 * d.n_mspheres + 32 * d.n_cubes + 128 * d.n_complex
+
+    def counted(self, depth, f64=False, accum_ptr=None):
+        """Algorithmic work per ray from a counted pass of the same launch shape at low spp.  Small scenes run the
+        leaf-list walk, which visits no nodes: their work is counted on the reference-order BVH walk
+        (RT_FLAG_FORCE_BVH); larger scenes are counted on the walk they run."""
+        c_spp = 16 if self.hs.desc.n_nodes < 4096 else 2
+        ptr = accum_ptr if accum_ptr is not None else self.accum.data_ptr()
+        st = self.ds.render_device(ptr, self.width, self.height, c_spp, depth, seed=1, sample_offset=0,
+                                   spp_per_launch=c_spp, stream=self.stream, stats=True, f64=f64)
+        on = "the executed walk (box tests count as nodes)"
+        if st["nodes_visited"] == 0 and self.hs.desc.n_nodes > 0:
+            st = self.ds.render_device(ptr, self.width, self.height, c_spp, depth, seed=1, sample_offset=0,
+                                       spp_per_launch=c_spp, stream=self.stream, stats=True, force_bvh=True)
+            on = "reference-order BVH walk of the same scene (RT_FLAG_FORCE_BVH)"
+        flops, byts = algorithmic_per_ray(st, self.width * self.height, st["launches"])
+        return flops, byts, on
+
+    def kernel_name(self, counted_on):
+        d = self.hs.desc
+        if "RT_FLAG_FORCE_BVH" in counted_on or d.n_nodes == 0:
+            return "render_persist_kernel"
+        return "render_refill_kernel"
+
+
+def roofline(wl, depth, rays, kernel_ms, launches, workload_key):
+    flops_per_ray, bytes_per_ray, counted_on = wl.counted(depth)
+    avg_launch_ms = kernel_ms / max(1, launches)
+    rays_per_launch = rays / max(1, launches)
+    tflops = flops_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e12
+    gbps = bytes_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    valu_frac, hbm_frac = tflops / PEAK_FP32_VALU_TFLOPS, gbps / PEAK_HBM_GBPS
+    # Which roof binds (SURVEY.md §8d): a scene whose nodes + primitives fit in one XCD's 4 MiB L2 (here: in LDS)
+    # never streams from HBM — its algorithmic bytes are served on-chip and the vector-FP32 issue rate is the
+    # roof; a scene larger than that is priced against HBM.
+    scene_bytes = wl.scene_bytes()
+    tr = measured_traffic(workload_key)
+    traffic = tr[0].get("bytes_per_launch") if tr else None
+    if scene_bytes <= 4 << 20:
+        r = {"bound": "valu_fp32", "achieved": tflops, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": valu_frac}
+    else:
+        r = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_frac}
+    r["traffic"] = traffic
+    if tr:
+        r["traffic_source"] = tr[1]
+        r["traffic_note"] = tr[0].get("note")
+    r.update({
+        "kernel": wl.kernel_name(counted_on), "algorithmic_work_counted_on": counted_on,
+        "avg_launch_ms": avg_launch_ms, "launches": launches,
+        "algorithmic_flops_per_ray": flops_per_ray, "algorithmic_bytes_per_ray": bytes_per_ray,
+        "algorithmic_tflops": tflops, "algorithmic_gbps": gbps,
+        "frac_valu_fp32": valu_frac, "frac_hbm": hbm_frac, "scene_bytes": scene_bytes,
+        "note": "no MFMA on this path; the binding peak is vector FP32 (157.3 TFLOP/s), not a matrix peak",
+    })
+    if r["bound"] == "hbm" and scene_bytes <= 200 << 20:
+        r["note"] += ("; this scene fits the 256 MiB Infinity Cache, so its algorithmic bytes are largely served on-die "
+                      "(L1/L2/MALL): frac prices them against HBM as the contract asks and can exceed 1 -- it is not an "
+                      "HBM utilisation (see profiles/ for EA counters)")
+    return r
+
+
+def time_renders(wl, spp, depth, steps, warmup, spp_per_launch=0, f64=False, accum=None, base_step=0):
+    """`warmup` untimed + `steps` timed renders on one GPU; returns (seconds, rays, kernel_ms, launches, nonfinite)."""
+    torch = wl.torch
+    ptr = (accum if accum is not None else wl.accum).data_ptr()
+    for i in range(warmup):
+        wl.ds.render_device(ptr, wl.width, wl.height, spp, depth, seed=1, sample_offset=(base_step + i) * spp,
+                            spp_per_launch=spp_per_launch, stream=wl.stream, f64=f64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rays = launches = nonfinite = 0
+    kernel_ms = 0.0
+    for i in range(steps):
+        st = wl.ds.render_device(ptr, wl.width, wl.height, spp, depth, seed=1,
+                                 sample_offset=(base_step + warmup + i) * spp, spp_per_launch=spp_per_launch,
+                                 stream=wl.stream, f64=f64)
+        rays += st["rays"]
+        kernel_ms += st["kernel_ms"]
+        launches += st["launches"]
+        nonfinite += st["nonfinite_samples"]
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, rays, kernel_ms, launches, nonfinite
+
+
+def f64_leg(wl, args):
+    """The same workload on the f64 audit kernel (reference-order walk, contraction off: the kernel that follows
+    the CPU oracle path for path): the throughput at the reference's own precision."""
+    torch = wl.torch
+    acc64 = torch.zeros((wl.height, wl.width, 3), dtype=torch.float64, device=wl.accum.device)
+    spp = args.f64_spp
+    secs, rays, kernel_ms, launches, _ = time_renders(wl, spp, args.max_depth, args.f64_steps, 1, f64=True, accum=acc64)
+    flops_per_ray, bytes_per_ray, _ = wl.counted(args.max_depth, f64=True, accum_ptr=acc64.data_ptr())
+    samples = float(wl.width) * wl.height * spp * args.f64_steps
+    avg_ms = kernel_ms / max(1, launches)
+    tflops = flops_per_ray * (rays / max(1, launches)) / (avg_ms * 1e-3) / 1e12
+    return {
+        "dtype": "f64", "entry": "rt_render_f64_device", "kernel": "render_kernel<double, ..., TRAV_REFERENCE>",
+        "workload": f"{args.scene} {wl.width}x{wl.height}, {spp} spp, max depth {args.max_depth}",
+        "steps": args.f64_steps, "warmup": 1, "ms_per_step": 1e3 * secs / args.f64_steps,
+        "value": rays / secs / 1e6, "unit": "Mrays/s", "msamples_per_s": samples / secs / 1e6,
+        "rays_per_sample": rays / samples,
+        "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tflops / PEAK_FP64_VALU_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms,
+                     "launches": launches, "algorithmic_flops_per_ray": flops_per_ray,
+                     "algorithmic_bytes_per_ray": bytes_per_ray},
+        "note": "walks every path to its end like the reference (no zero-throughput early exit, NaN samples poison the "
+                "pixel): compare with the f32 line in samples/s, not rays/s",
+    }
+
+
+OTHER_CONFIGS = [
+    # (tag, scene, width, aspect, n, full spp, bench spp, depth)
+    ("C1", "random_scene", 400, 16.0 / 9.0, 0, 100, 100, 50),
+    ("C3", "final_scene", 1024, 1.0, 0, 10000, 512, 50),
+    ("C4", "bvh_stress", 3840, 16.0 / 9.0, 1000000, 256, 4, 50),
+]
+
+
+def other_configs(R, torch, device):
+    """BASELINE.json configs C1, C3, C4 on one GPU at bounded spp (the rates are spp-independent once a launch is
+    long enough; C1 is run at its full size)."""
+    lines = []
+    for tag, scene, width, aspect, n, full_spp, spp, depth in OTHER_CONFIGS:
+        wl = Workload(R, torch, scene, width, aspect, n, device)
+        steps = 5 if tag == "C1" else 2
+        secs, rays, kernel_ms, launches, nonfinite = time_renders(wl, spp, depth, steps, 1)
+        key = f"{scene} {width}x{wl.height}, {spp} spp, max depth {depth}" + (f", n={n}" if n else "")
+        rl = roofline(wl, depth, rays, kernel_ms, launches, key)
+        samples = float(width) * wl.height * spp * steps
+        lines.append({"config": tag, "workload": key, "full_config_spp": full_spp, "steps": steps,
+                      "ms_per_step": 1e3 * secs / steps, "value": rays / secs / 1e6, "unit": "Mrays/s",
+                      "msamples_per_s": samples / secs / 1e6, "rays_per_sample": rays / samples,
+                      "nonfinite_samples_dropped": nonfinite, "dtype": "f32",
+                      "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+                                                      "avg_launch_ms", "algorithmic_flops_per_ray",
+                                                      "algorithmic_bytes_per_ray", "frac_valu_fp32", "frac_hbm",
+                                                      "scene_bytes")}})
+        del wl
+        torch.cuda.empty_cache()
+    return lines
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,7 +272,14 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="scene 7 (bvh_stress): number of spheres")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--no-f64-leg", action="store_true")
+    ap.add_argument("--f64-spp", type=int, default=256, help="samples per pixel of the f64 leg's step")
+    ap.add_argument("--f64-steps", type=int, default=2)
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)  # nothing above has touched a GPU (torch is not even imported yet)
 
     import torch
     import torch.distributed as dist
@@ -72,7 +291,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus):
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # RT_BENCH_REHEARSAL=1: rehearse the multi-rank path on a ONE-GPU box (every rank on device 0, gloo
@@ -88,24 +307,24 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    width = args.width
-    height = R.image_height(width, args.aspect)
-    hs = R.HostScene(args.scene, args.aspect, n=args.n)
-    ds = R.DeviceScene(hs, local_rank)
+    wl = Workload(R, torch, args.scene, args.width, args.aspect, args.n, local_rank)
+    width, height = wl.width, wl.height
     dev = torch.device("cuda", local_rank)
-    accum = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
-    rgb8 = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
     from raytracer_amd import _ffi as F
 
     def step(i):
         # every step renders fresh global sample indices, so no step can reuse another's result
         offset = (i * world + rank) * args.spp
-        st = ds.render_device(accum.data_ptr(), width, height, args.spp, args.max_depth, seed=1,
-                              sample_offset=offset, spp_per_launch=args.spp_per_launch, stream=stream)
-        allreduce_accum(accum)
-        F.check_hip(F.hip.rt_tonemap_device(local_rank, accum.data_ptr(), width * height, args.spp * world,
-                                            rgb8.data_ptr(), stream))
+        st = wl.ds.render_device(wl.accum.data_ptr(), width, height, args.spp, args.max_depth, seed=1,
+                                 sample_offset=offset, spp_per_launch=args.spp_per_launch, stream=wl.stream)
+        if rehearsal and world > 1:  # gloo reduces host tensors
+            host = wl.accum.cpu()
+            allreduce_accum(host)
+            wl.accum.copy_(host)
+        else:
+            allreduce_accum(wl.accum)
+        F.check_hip(F.hip.rt_tonemap_device(local_rank, wl.accum.data_ptr(), width * height, args.spp * world,
+                                            wl.rgb8.data_ptr(), wl.stream))
         return st
 
     def sync():
@@ -130,7 +349,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -142,8 +361,10 @@ def main():
 
     if rank == 0:
         samples = float(width) * height * args.spp * world * args.steps
+        workload = (f"{args.scene} {width}x{height}, {args.spp} spp per GPU, max depth {args.max_depth}"
+                    + (f", n={args.n}" if args.n else ""))
         out = {
-            "metric": "Mrays/s (whole node) 1/2/4/8 MI355X, Cornell box 1024² 4096spp",
+            "metric": METRIC,
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -155,68 +376,34 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
-            "config": {"workload": f"{args.scene} {width}x{height}, {args.spp} spp per GPU, max depth {args.max_depth}"
-                                   + (f", n={args.n}" if args.n else ""),
-                       "scene_seed": 5, "bvh_seed": 7, "render_seed": 1,
+            "config": {"workload": workload, "scene_seed": 5, "bvh_seed": 7, "render_seed": 1,
                        "parallelism": f"sample-sharded x{world}, RCCL sum all-reduce of the accumulator"},
             "msamples_per_s": samples / elapsed / 1e6,
             "rays_per_sample": total_rays / samples,
             "nonfinite_samples_dropped": nonfinite,
         }
-        # roofline of the dominant kernel (render_kernel<float>): live HIP-event duration on the launch
-        # stream, algorithmic work from a counted pass of the same launch shape at 16 spp
-        # (small scenes run the leaf-list walk, which visits no nodes: their algorithmic work is counted on
-        # the reference-order BVH walk, RT_FLAG_FORCE_BVH; larger scenes are counted on the walk they run)
-        c_spp = 16 if hs.desc.n_nodes < 4096 else 2
-        st_c = ds.render_device(accum.data_ptr(), width, height, c_spp, args.max_depth, seed=1, sample_offset=0,
-                                spp_per_launch=c_spp, stream=stream, stats=True)
-        counted_on = "executed ordered BVH walk (box tests count as nodes)"
-        if st_c["nodes_visited"] == 0 and hs.desc.n_nodes > 0:
-            st_c = ds.render_device(accum.data_ptr(), width, height, c_spp, args.max_depth, seed=1, sample_offset=0,
-                                    spp_per_launch=c_spp, stream=stream, stats=True, force_bvh=True)
-            counted_on = "reference-order BVH walk of the same scene (RT_FLAG_FORCE_BVH)"
-        flops_per_ray, bytes_per_ray = algorithmic_per_ray(st_c, width * height, st_c["launches"])
-        avg_launch_ms = kernel_ms / max(1, launches)
-        rays_per_launch = rays / max(1, launches)
-        tflops = flops_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e12
-        gbps = bytes_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        valu_frac, hbm_frac = tflops / PEAK_FP32_VALU_TFLOPS, gbps / PEAK_HBM_GBPS
-        # Which roof binds: a scene whose nodes + primitives fit in one XCD's 4 MiB L2 (here:
-        # in LDS) never streams from HBM — its algorithmic bytes are served on-chip and the vector-FP32
-        # issue rate is the roof; a scene larger than that is priced against HBM.
-        d = hs.desc
-        scene_bytes = 32 * d.n_nodes + 16 * d.n_spheres + 48 * d.n_mspheres + 32 * d.n_cubes + 128 * d.n_complex
-        # measured once with PMC counters for the default workload (profiles/r01j_traffic.txt); null otherwise
-        default_workload = (args.scene == "cornell_box" and width == 1024 and args.spp == 4096 and launches == args.steps)
-        traffic = 3.2e9 if default_workload else None
-        if scene_bytes <= 4 << 20:
-            out["roofline"] = {"bound": "valu_fp32", "achieved": tflops, "peak": PEAK_FP32_VALU_TFLOPS,
-                               "unit": "TFLOP/s", "frac": valu_frac, "traffic": traffic,
-                               "traffic_note": "bytes per launch at the L2<->fabric boundary (upper bound: 5.03e7 float-atomic "
-                                               "requests x 64 B + 4.5 MB reads; profiles/r01j_traffic.txt); the algorithmic "
-                                               "bytes are served from LDS" if traffic else None}
-        else:
-            out["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                               "frac": hbm_frac, "traffic": None}
-        out["roofline"].update({
-            "kernel": "render_refill_kernel" if "ordered" in counted_on else "render_persist_kernel",
-            "algorithmic_work_counted_on": counted_on, "avg_launch_ms": avg_launch_ms, "launches": launches,
-            "algorithmic_flops_per_ray": flops_per_ray, "algorithmic_bytes_per_ray": bytes_per_ray,
-            "algorithmic_tflops": tflops, "algorithmic_gbps": gbps,
-            "frac_valu_fp32": valu_frac, "frac_hbm": hbm_frac, "scene_bytes": scene_bytes,
-            "note": "no MFMA on this path; the binding peak is vector FP32 (157.3 TFLOP/s), not a matrix peak",
-        })
-        if out["roofline"]["bound"] == "hbm" and scene_bytes <= 200 << 20:
-            out["roofline"]["note"] += ("; this scene fits the 256 MiB Infinity Cache, so its algorithmic bytes are largely "
-                                        "served on-die (L1/L2/MALL): frac prices them against HBM as the contract asks "
-                                        "and can exceed 1 -- it is not an HBM utilisation (see profiles/ for EA counters)")
+        # roofline of the dominant kernel: live HIP-event duration on the launch stream (rt_stats.kernel_ms, events
+        # recorded on the stream the kernels are launched on), algorithmic work from a counted pass
+        key = (f"{args.scene} {width}x{height}, {args.spp} spp, max depth {args.max_depth}" + (f", n={args.n}" if args.n else ""))
+        out["roofline"] = roofline(wl, args.max_depth, rays, kernel_ms, launches, key)
+        if world == 1 and not args.no_f64_leg:
+            out["f64_leg"] = f64_leg(wl, args)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, width, height)
+            cb = cpu_baseline(args, width, height)
+            out["cpu_baseline"] = cb
+            # like for like: the f32 kernel stops zero-throughput paths (fewer rays per sample than the oracle,
+            # which walks them like the reference), so the honest ratio is in SAMPLES per second
+            out["gpu_vs_cpu_msamples"] = out["msamples_per_s"] / cb["msamples_per_s"]
+            if "f64_leg" in out:
+                out["f64_leg"]["gpu_vs_cpu_msamples"] = out["f64_leg"]["msamples_per_s"] / cb["msamples_per_s"]
+        if world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_configs(R, torch, local_rank)
         print(json.dumps(out), flush=True)
 
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 def cpu_baseline(args, width, height):
@@ -245,8 +432,9 @@ def cpu_baseline(args, width, height):
             "sample": f"{args.scene} {width}x{height} at {spp} spp, depth {args.max_depth} ({secs:.1f} s, "
                       f"{cnt['rays']} rays; {secs_counted:.1f} s with the checker's work counters on); "
                       "rates are spp-independent",
-            "msamples_per_s": width * height * spp / secs / 1e6}
+            "msamples_per_s": width * height * spp / secs / 1e6,
+            "rays_per_sample": cnt["rays"] / float(width * height * spp)}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -26,6 +26,7 @@ extern "C" {
 #endif
 
 #define RT_ABI_VERSION 1u
+#define RT_MAX_BVH_HEIGHT 63u       /* nodes on a root-to-leaf path: 4 B per level and lane of LDS, 64 KiB per workgroup */
 
 typedef struct rt_scene rt_scene; /* opaque: one per (scene, device) */
 
@@ -34,7 +35,7 @@ typedef enum rt_status {
   RT_ERR_BAD_ARG = 1,      /* null pointer, size mismatch, out-of-range index, empty shutter */
   RT_ERR_HIP = 2,          /* a hip* call failed (no device, OOM, launch failure) */
   RT_ERR_UNSUPPORTED = 3,  /* scene uses nesting the flat format cannot express */
-  RT_ERR_STACK_DEPTH = 4   /* BVH height exceeds the LDS traversal stack */
+  RT_ERR_STACK_DEPTH = 4   /* BVH height exceeds the LDS traversal stack (RT_MAX_BVH_HEIGHT) */
 } rt_status;
 
 /* ---- node / leaf references ------------------------------------------------------------
@@ -230,9 +231,23 @@ int rt_render_f64(rt_scene* scene, const rt_camera* cam, const rt_params* params
  * enqueued on `stream` (a hipStream_t, may be null).  If accumulate != 0 the samples are
  * added to the buffer's contents, else the buffer is overwritten.  If stats is non-null the
  * call synchronises the stream before returning.  This is what the multi-GPU path uses:
- * each rank renders its sample range, then one RCCL sum all-reduce merges the buffers.    */
+ * each rank renders its sample range, then one RCCL sum all-reduce merges the buffers.
+ * ONE STREAM AT A TIME PER SCENE: every call on an rt_scene shares that scene's counter block (work
+ * counters, the persistent kernels' unit counter) and its two timing events, so a call may only be
+ * enqueued once the previous call on the same scene has been enqueued on the SAME stream, or has
+ * completed; calls on different streams that overlap on one scene race (skipped or doubled sample
+ * units).  Use one rt_scene per stream.
+ * NON-FINITE SAMPLES (f32 entries: rt_render, rt_render_device, rt_render_multi): a sample whose radiance
+ * is NaN or infinite is dropped and counted in rt_stats.nonfinite_samples, the divisor stays spp; the
+ * reference adds it to the pixel (main.rs:165), which then quantises to 0 (main.rs:59-61, Q9/Q10 of
+ * SURVEY.md 7.3).  rt_render_f64 keeps the reference's behaviour.  Parity of the f32 behaviour on such
+ * pixels is unpinned: no reference output holds one.                                              */
 int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
                      float* accum_rgb_device, int accumulate, void* stream, rt_stats* stats);
+/* The f64 audit kernel into DEVICE memory (f64 [h][w][3] SUM): what bench.py times as the
+ * reference-precision leg (the reference computes in f64 throughout, alias.rs:4-7).        */
+int rt_render_f64_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+                         double* accum_rgb_device, int accumulate, void* stream, rt_stats* stats);
 
 /* Replaces: the same closure (main.rs:154-167) with rayon's worker pool (main.rs:157) lifted from
  * cores to the GPUs of one node, in ONE process: one host thread per entry of `devices` builds its

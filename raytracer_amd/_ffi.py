@@ -97,13 +97,13 @@ class RthRenderOpts(C.Structure):
 # every symbol include/rt.h and include/rt_host.h declare (tests check the export lists against the headers)
 RT_SYMBOLS = [
     "rt_scene_create", "rt_scene_destroy", "rt_primary_hits", "rt_primary_hits_f64", "rt_primary_hits_fast", "rt_render",
-    "rt_render_f64", "rt_render_device", "rt_render_multi", "rt_debug_build_tree", "rt_tonemap", "rt_tonemap_device", "rt_kat_sphere_uv", "rt_kat_rotate",
+    "rt_render_f64", "rt_render_device", "rt_render_f64_device", "rt_render_multi", "rt_debug_build_tree", "rt_tonemap", "rt_tonemap_device", "rt_kat_sphere_uv", "rt_kat_rotate",
     "rt_kat_philox", "rt_device_count", "rt_abi_version", "rt_last_error",
 ]
 RTH_SYMBOLS = [
     "rth_scene_build", "rth_scene_free", "rth_scene_desc", "rth_scene_camera", "rth_scene_object_count",
     "rth_scene_bvh_calls", "rth_camera_new", "rth_render", "rth_image_height", "rth_write_png", "rth_rotate",
-    "rth_bvh_axis",
+    "rth_bvh_axis", "rth_texture_from_rgb8_file", "rth_texture_free",
     "rth_last_error",
 ]
 
@@ -134,6 +134,7 @@ hip.rt_primary_hits_fast.argtypes = hip.rt_primary_hits.argtypes
 hip.rt_render.argtypes = [_p, C.POINTER(RtCamera), C.POINTER(RtParams), _p, C.POINTER(RtStats)]
 hip.rt_render_f64.argtypes = hip.rt_render.argtypes
 hip.rt_render_device.argtypes = [_p, C.POINTER(RtCamera), C.POINTER(RtParams), _p, C.c_int, _p, C.POINTER(RtStats)]
+hip.rt_render_f64_device.argtypes = hip.rt_render_device.argtypes
 hip.rt_render_multi.argtypes = [C.c_int, C.POINTER(C.c_int), _p, C.POINTER(RtCamera), C.POINTER(RtParams), _p,
                                 C.POINTER(RtStats)]
 hip.rt_debug_build_tree.argtypes = [C.c_uint32, _p, _p, C.c_uint32, _p, C.POINTER(C.c_uint32)]
@@ -162,6 +163,9 @@ host.rth_render.argtypes = [C.POINTER(RthRenderOpts), _p, _p, _u32p, C.POINTER(R
 host.rth_image_height.argtypes = [C.c_uint32, C.c_double]
 host.rth_image_height.restype = C.c_uint32
 host.rth_write_png.argtypes = [C.c_char_p, _p, C.c_uint32, C.c_uint32]
+host.rth_texture_from_rgb8_file.argtypes = [C.c_char_p, _u32p, _u32p, C.POINTER(_u8p)]
+host.rth_texture_free.argtypes = [_u8p]
+host.rth_texture_free.restype = None
 host.rth_rotate.argtypes = [C.c_double, _p, _p, _p]
 host.rth_rotate.restype = None
 host.rth_bvh_axis.argtypes = [C.c_uint64, C.c_uint32]

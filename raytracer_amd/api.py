@@ -38,6 +38,17 @@ def write_earthmap_ppm(path):
         f.write(rgb8.tobytes())
 
 
+def texture_from_file(path):
+    """Texture::new_image (texture.rs:25-31) through the host library: a binary PPM (P6, maxval 255) as RGB8
+    [h][w][3].  A missing or malformed file raises RtError(RT_ERR_BAD_ARG) where the reference panics."""
+    w, h, px = C.c_uint32(), C.c_uint32(), F._u8p()
+    F.check_host(F.host.rth_texture_from_rgb8_file(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px)))
+    try:
+        return np.ctypeslib.as_array(px, shape=(h.value, w.value, 3)).copy()
+    finally:
+        F.host.rth_texture_free(px)
+
+
 def write_png(path, rgb8):
     """image.save(path) of main.rs:176 for an RGB8 image [h][w][3] (8-bit RGB PNG, stored deflate)."""
     rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
@@ -177,14 +188,16 @@ class DeviceScene:
         return accum, st.as_dict()
 
     def render_device(self, accum_ptr, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0,
-                      accumulate=False, stream=None, want_stats=True, stats=False, camera=None, force_bvh=False):
-        """Same, into DEVICE memory (accum_ptr = raw device address of a float32 [h][w][3] buffer)."""
+                      accumulate=False, stream=None, want_stats=True, stats=False, camera=None, force_bvh=False,
+                      f64=False):
+        """Same, into DEVICE memory (accum_ptr = raw device address of a float32 [h][w][3] buffer; float64 with
+        f64=True: rt_render_f64_device)."""
         p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh)
         st = F.RtStats()
         cam = camera if camera is not None else self.host.camera
-        F.check_hip(F.hip.rt_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(accum_ptr),
-                                           1 if accumulate else 0, C.c_void_p(stream or 0),
-                                           C.byref(st) if want_stats else None))
+        fn = F.hip.rt_render_f64_device if f64 else F.hip.rt_render_device
+        F.check_hip(fn(self._h, C.byref(cam), C.byref(p), C.c_void_p(accum_ptr), 1 if accumulate else 0,
+                       C.c_void_p(stream or 0), C.byref(st) if want_stats else None))
         return st.as_dict() if want_stats else None
 
 

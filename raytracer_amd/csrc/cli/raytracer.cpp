@@ -80,41 +80,6 @@ bool parse_f64(const std::string& s, double& out) {
   return *end == 0;
 }
 
-// P6 reader: "P6 <w> <h> 255\n" + w*h*3 bytes, '#' comments allowed in the header
-bool read_ppm(const std::string& path, std::vector<uint8_t>& texels, uint32_t& w, uint32_t& h) {
-  FILE* f = std::fopen(path.c_str(), "rb");
-  if (!f) return false;
-  auto token = [&](std::string& t) {
-    t.clear();
-    int c;
-    for (;;) {
-      c = std::fgetc(f);
-      if (c == '#') {
-        while (c != '\n' && c != EOF) c = std::fgetc(f);
-      } else if (c == EOF || !std::isspace(c)) {
-        break;
-      }
-    }
-    while (c != EOF && !std::isspace(c)) {
-      t.push_back((char)c);
-      c = std::fgetc(f);
-    }
-    return !t.empty();
-  };
-  std::string magic, sw, sh, smax;
-  uint64_t vw = 0, vh = 0, vmax = 0;
-  bool ok = token(magic) && magic == "P6" && token(sw) && token(sh) && token(smax) && parse_u64(sw, 1u << 16, vw) &&
-            parse_u64(sh, 1u << 16, vh) && parse_u64(smax, 255, vmax) && vmax == 255 && vw > 0 && vh > 0;
-  if (ok) {
-    texels.resize((size_t)vw * vh * 3);
-    ok = std::fread(texels.data(), 1, texels.size(), f) == texels.size();
-    w = (uint32_t)vw;
-    h = (uint32_t)vh;
-  }
-  std::fclose(f);
-  return ok;
-}
-
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -211,16 +176,20 @@ int main(int argc, char** argv) {
   ro.scene.scene_seed = o.scene_seed;
   ro.scene.bvh_seed = o.bvh_seed;
   ro.scene.n = o.n;
-  std::vector<uint8_t> texels;
+  uint8_t* texels = nullptr;
+  struct TexelGuard {
+    uint8_t*& p;
+    ~TexelGuard() { rth_texture_free(p); }
+  } texel_guard{texels};
   if (o.scene == 2 || o.scene == 4 || o.scene == 8 || o.scene == 11) {  // Texture::new_image (texture.rs:25-31, scenes.rs:126)
-    if (!read_ppm(o.earthmap, texels, ro.scene.tex_width, ro.scene.tex_height)) {
+    if (rth_texture_from_rgb8_file(o.earthmap.c_str(), &ro.scene.tex_width, &ro.scene.tex_height, &texels) != RT_OK) {
       std::fprintf(stderr,
                    "error: scene %u needs the earth texture: cannot read '%s' as a binary PPM (P6, maxval 255).\n"
                    "       write it with: python -c \"import raytracer_amd as R; R.write_earthmap_ppm('assets/earthmap.ppm')\"\n",
                    o.scene, o.earthmap.c_str());
       return 1;
     }
-    ro.scene.texels = texels.data();
+    ro.scene.texels = texels;
   }
   ro.image_width = image_width;
   ro.samples_per_pixel = o.samples_per_pixel;

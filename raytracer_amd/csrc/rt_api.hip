@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -95,7 +96,11 @@ struct DeviceBuffers {
   }
 };
 
-constexpr uint32_t MAX_STACK_DEPTH = 64;
+// The reference-order kernels keep a 4-byte stack entry per level and lane in dynamic LDS (launch_impl.hpp:
+// stack_depth * 256 * 4 B) beside <= 320 B of static tables (s_lights); the default per-workgroup limit is 64 KiB,
+// so 63 levels is what fits (63 * 1024 + 320 = 64832 B).  The ordered walk's own tree (6 B per level and lane) is
+// capped at ceil(log2 n) + 6 <= 34 levels by its builder.
+constexpr uint32_t MAX_STACK_DEPTH = 63;
 
 // What rt_scene_create learns from one left-first DFS of the tree.
 struct TreeFacts {
@@ -632,11 +637,6 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
     return fail(RT_ERR_STACK_DEPTH, "rt_scene_create: BVH height %u exceeds the %u-entry LDS stack", tree_height,
                 MAX_STACK_DEPTH);
 
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (device < 0 || device >= ndev) return fail(RT_ERR_BAD_ARG, "rt_scene_create: device %d of %d", device, ndev);
-  HIP_TRY(hipSetDevice(device));
-
   // One left-first DFS (the order the reference's recursion reaches the leaves): DFS rank of every
   // leaf, its bounds, and whether every box in the tree really bounds what is below it.  The
   // reference's Rotate::bounding_box does not always (it can clip the object), and then
@@ -661,10 +661,12 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
       }
       return true;
     };
+    uint32_t nodes_reached = 0;
     while (!todo.empty()) {
       Todo cur = todo.back();
       todo.pop_back();
       if (!(cur.ref & RT_REF_LEAF)) {
+        ++nodes_reached;
         const double* nb = d->node_box + 6 * (size_t)cur.ref;
         if (!inside(nb, nb + 3, cur.parent)) facts.conservative = false;
         todo.push_back({d->node_right[cur.ref], cur.ref});
@@ -702,11 +704,24 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
         if (cx.medium_pos != REF_NONE && cx.medium_pos != 0) facts.linear_ok = false;  // records keep media outermost
       }
     }
+    // every node must hang below the root (pre-order indices make a node reachable at most once): an orphan node's
+    // leaves would have no DFS rank, and nothing the reference builds (hittable.rs:159-206) has one
+    if (nodes_reached != d->n_nodes)
+      return fail(RT_ERR_BAD_ARG, "rt_scene_create: %u of %u nodes are not reachable from the root", d->n_nodes - nodes_reached,
+                  d->n_nodes);
+  } else if (d->n_nodes != 0) {
+    return fail(RT_ERR_BAD_ARG, "rt_scene_create: an empty world (root = RT_REF_NONE) cannot carry nodes");
   }
   if (!facts.conservative || facts.leaf_refs.size() > LIN_MAX_LEAVES) facts.linear_ok = false;
   std::vector<uint32_t> linear;
   if (facts.linear_ok) linear = facts.leaf_refs;
   for (uint32_t i = 0; i < d->n_complex; ++i) complexes[i].rank = facts.rank_complex[i];
+
+  // (the description is validated in full before the first HIP call: a bad scene is RT_ERR_BAD_ARG with or without a GPU)
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(RT_ERR_BAD_ARG, "rt_scene_create: device %d of %d", device, ndev);
+  HIP_TRY(hipSetDevice(device));
 
   rt_scene* s = new rt_scene;
   s->device = device;
@@ -839,25 +854,47 @@ void stats_to_abi(const DeviceStats& d, rt_stats* o) {
   o->nonfinite_samples = d.v[ST_NONFINITE];
 }
 
+// rt_params checks shared by every render entry (hoisted so that rt_render_multi can refuse a bad request before it
+// builds G scenes): u = (x + xi) / (w - 1) needs w, h >= 2 (main.rs:161-163); pixel and sample indices are 32-bit.
+int check_params(const rt_params* p, const char* who) {
+  if (!p) return fail(RT_ERR_BAD_ARG, "%s: null params", who);
+  if (p->width < 2 || p->height < 2)
+    return fail(RT_ERR_BAD_ARG, "%s: image must be at least 2x2 (main.rs:161-163 divides by w-1, h-1)", who);
+  if ((uint64_t)p->width * p->height > 0xFFFFFFFFull / 3) return fail(RT_ERR_BAD_ARG, "%s: image too large", who);
+  if (p->sample_offset + p->spp > 0xFFFFFFFFull) return fail(RT_ERR_BAD_ARG, "%s: sample index exceeds 32 bits", who);
+  return RT_OK;
+}
+
 // Enqueue the launches of one render call on `stream`; accum is device memory.
+// blocks / n_blocks: the DeviceStats scratch.  n_blocks == 1 (the scene's own block, allocated by rt_scene_create):
+// every launch uses it, its unit counter is re-zeroed between launches.  n_blocks > 1 (rt_render_device_noalloc: the
+// file-scope scratch, 256-byte slots): launch i uses slot i, all slots are zeroed by one memset up front and the
+// counters are summed on the host.
+constexpr size_t NOALLOC_SLOT_BYTES = 256;
 template <typename R>
 int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d_accum, int accumulate,
-                     hipStream_t stream, rt_stats* stats) {
+                     hipStream_t stream, rt_stats* stats, unsigned char* blocks = nullptr, uint32_t n_blocks = 1) {
   if (!s || !p || !d_accum) return fail(RT_ERR_BAD_ARG, "rt_render: null argument");
   if (int rc = check_camera(cam)) return rc;
-  if (p->width < 2 || p->height < 2)  // u = (x + ξ) / (w - 1), main.rs:161
-    return fail(RT_ERR_BAD_ARG, "rt_render: image must be at least 2x2 (main.rs:161-163 divides by w-1, h-1)");
-  if ((uint64_t)p->width * p->height > 0xFFFFFFFFull / 3) return fail(RT_ERR_BAD_ARG, "rt_render: image too large");
-  if (p->sample_offset + p->spp > 0xFFFFFFFFull) return fail(RT_ERR_BAD_ARG, "rt_render: sample index exceeds 32 bits");
+  if (int rc = check_params(p, "rt_render")) return rc;
+  // One launch renders up to 4096 samples of every pixel: a lane keeps regenerating samples in its loop, so
+  // long launches amortise the wave start-up and the tail in which the lanes of a wave run out of
+  // samples one by one (measured on Cornell 1024^2 x 4096 spp: 64 per launch 40.3, 256: 43.1, 4096: 45.2 Grays/s).
+  const uint32_t per_launch = p->spp_per_launch ? p->spp_per_launch : 4096u;
+  const uint32_t n_launches = (p->spp + per_launch - 1) / per_launch;
+  const bool slots = blocks != nullptr;
+  if (slots && n_launches > n_blocks)
+    return fail(RT_ERR_BAD_ARG,
+                "rt_render_device_noalloc: %u spp at %u per launch is %u launches, the static scratch holds %u: raise "
+                "spp_per_launch or split the call",
+                p->spp, per_launch, n_launches, n_blocks);
+  if (!slots) blocks = reinterpret_cast<unsigned char*>(s->dstats);
+  auto block = [&](uint32_t i) { return reinterpret_cast<DeviceStats*>(blocks + (slots ? (size_t)i * NOALLOC_SLOT_BYTES : 0)); };
   HIP_TRY(hipSetDevice(s->device));
   const bool want_stats = (p->flags & RT_FLAG_STATS) != 0;
   CameraView<R> cv = to_camera<R>(*cam);
   const SceneView<R>& sv = Side<R>::get(s).view;
-  // One launch renders up to 4096 samples of every pixel: a lane keeps regenerating samples in its loop, so
-  // long launches amortise the wave start-up and the tail in which the lanes of a wave run out of
-  // samples one by one (measured on Cornell 1024^2 x 4096 spp: 64 per launch 40.3, 256: 43.1, 4096: 45.2 Grays/s).
-  uint32_t per_launch = p->spp_per_launch ? p->spp_per_launch : 4096u;
-  HIP_TRY(hipMemsetAsync(s->dstats, 0, sizeof(DeviceStats), stream));
+  HIP_TRY(hipMemsetAsync(blocks, 0, slots ? std::max<size_t>(n_launches, 1) * NOALLOC_SLOT_BYTES : sizeof(DeviceStats), stream));
   HIP_TRY(hipEventRecord(s->ev0, stream));
   uint32_t done = 0, launches = 0;
   bool first = true;
@@ -868,9 +905,9 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
     LaunchShape sh = make_shape(s, p->width, p->height, n, sizeof(R) == 4 && !(p->flags & RT_FLAG_FORCE_BVH), cam, p->max_depth);
     int acc = (accumulate || !first) ? 1 : 0;
     if ((sh.splits > 1 || sh.unit_samples > 0) && !acc) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
-    if (sh.unit_samples > 0) HIP_TRY(hipMemsetAsync(&s->dstats->unit_counter, 0, sizeof(unsigned int), stream));
+    if (sh.unit_samples > 0 && !slots && !first) HIP_TRY(hipMemsetAsync(&s->dstats->unit_counter, 0, sizeof(unsigned int), stream));
     HIP_TRY(Side<R>::render(sv, cv, p->width, p->height, (uint32_t)(p->sample_offset + done), n, p->max_depth, p->seed,
-                            acc, want_stats, d_accum, s->dstats, sh, stream));
+                            acc, want_stats, d_accum, block(launches), sh, stream));
     done += n;
     first = false;
     ++launches;
@@ -878,8 +915,21 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
   HIP_TRY(hipEventRecord(s->ev1, stream));
   if (stats) {
     DeviceStats hs;
-    HIP_TRY(hipMemcpyAsync(&hs, s->dstats, sizeof(hs), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    std::memset(&hs, 0, sizeof(hs));
+    if (!slots) {
+      HIP_TRY(hipMemcpyAsync(&hs, s->dstats, sizeof(hs), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+    } else {
+      alignas(16) unsigned char image[NOALLOC_SLOT_BYTES * 64];
+      if (launches) HIP_TRY(hipMemcpyAsync(image, blocks, (size_t)launches * NOALLOC_SLOT_BYTES, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      for (uint32_t i = 0; i < launches; ++i) {
+        DeviceStats one;
+        std::memcpy(&one, image + (size_t)i * NOALLOC_SLOT_BYTES, sizeof(one));
+        for (int k = 0; k < 17; ++k) hs.v[k] += one.v[k];
+        for (int k = 0; k < 8; ++k) hs.stamp[k] += one.stamp[k];
+      }
+    }
     std::memset(stats, 0, sizeof(*stats));
     stats_to_abi(hs, stats);
     if (getenv("RT_PRINT_STAMPS")) {
@@ -898,6 +948,7 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
 template <typename R>
 int render_to_host(rt_scene* s, const rt_camera* cam, const rt_params* p, R* h_accum, rt_stats* stats) {
   if (!s || !p || !h_accum) return fail(RT_ERR_BAD_ARG, "rt_render: null argument");
+  if (int rc = check_params(p, "rt_render")) return rc;  // before the accumulator is sized from them
   HIP_TRY(hipSetDevice(s->device));
   size_t bytes = (size_t)p->width * p->height * 3 * sizeof(R);
   R* d = nullptr;
@@ -975,7 +1026,10 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* p, floa
                      void* stream, rt_stats* stats) {
   return render_on_device<float>(s, cam, p, d_accum, accumulate, (hipStream_t)stream, stats);
 }
-
+int rt_render_f64_device(rt_scene* s, const rt_camera* cam, const rt_params* p, double* d_accum, int accumulate,
+                         void* stream, rt_stats* stats) {
+  return render_on_device<double>(s, cam, p, d_accum, accumulate, (hipStream_t)stream, stats);
+}
 // One host thread per device (rayon's "shared immutable scene, independent workers" model,
 // main.rs:157-169, lifted from cores to GPUs): device g renders samples [g*spp/G, (g+1)*spp/G) of
 // every pixel into its own HBM accumulator; the shards are then summed on devices[0].  Every peer
@@ -986,6 +1040,7 @@ int rt_render_multi(int n_dev, const int* devices, const rt_scene_desc* desc, co
                     float* accum, rt_stats* per_dev) {
   if (n_dev < 1 || !devices || !desc || !p || !accum) return fail(RT_ERR_BAD_ARG, "rt_render_multi: bad argument");
   if (int rc = check_camera(cam)) return rc;
+  if (int rc = check_params(p, "rt_render_multi")) return rc;  // before G scenes and G accumulators are built
   if (n_dev > 64) return fail(RT_ERR_BAD_ARG, "rt_render_multi: at most 64 devices");
   const size_t n_floats = (size_t)p->width * p->height * 3;
   struct Shard {
@@ -1074,7 +1129,9 @@ void rt_tonemap(const float* accum, uint64_t n_pixels, uint64_t spp, uint8_t* rg
 }
 
 int rt_tonemap_device(int device, const float* d_accum, uint64_t n_pixels, uint64_t spp, uint8_t* d_rgb8, void* stream) {
-  if (!d_accum || !d_rgb8 || spp == 0) return fail(RT_ERR_BAD_ARG, "rt_tonemap_device: bad argument");
+  // spp == 0 is not refused: like rt_tonemap (and like main.rs:167, `pixel_color / 0`) it divides by zero, and
+  // 0/0 = NaN quantises to 0 (main.rs:59-61), anything else to 255
+  if (!d_accum || !d_rgb8) return fail(RT_ERR_BAD_ARG, "rt_tonemap_device: null argument");
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(launch_tonemap(d_accum, 3 * n_pixels, 1.0f / (float)spp, d_rgb8, (hipStream_t)stream));
   return RT_OK;

@@ -97,6 +97,56 @@ def test_scene_create_validates_before_touching_the_device():
 
     assert F.hip.rt_scene_create(0, None, C.byref(out)) == F.RT_ERR_BAD_ARG
 
+    def orphan_node(d):  # node 4..6 cut off from the root: pre-order indices stay legal, reachability does not
+        left = np.ctypeslib.as_array(d.node_left, shape=(d.n_nodes,)).copy()
+        right = np.ctypeslib.as_array(d.node_right, shape=(d.n_nodes,)).copy()
+        inner = [i for i in range(d.n_nodes) if not (right[i] & 0x80000000) or not (left[i] & 0x80000000)]
+        i = inner[0]
+        if not (right[i] & 0x80000000):
+            right[i] = left[d.n_nodes - 1]   # a leaf that is then referenced twice, or an orphaned subtree: refused either way
+        else:
+            left[i] = right[d.n_nodes - 1]
+        d.node_left = left.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.node_right = right.ctypes.data_as(C.POINTER(C.c_uint32))
+        return left, right
+    rc, msg, _ = attempt(orphan_node)
+    assert rc == F.RT_ERR_BAD_ARG and ("reachable" in msg or "more than one" in msg), msg
+
+
+def test_tree_height_limit_is_checked_at_create_time():
+    """RT_MAX_BVH_HEIGHT = 63: what the LDS stack of the reference-order kernels holds."""
+    from desc_util import chain_desc
+    from raytracer_amd import _ffi as F
+    out = C.c_void_p()
+    d, keep = chain_desc(65)  # 64 nodes on the root-to-leaf path
+    rc = F.hip.rt_scene_create(0, C.byref(d), C.byref(out))
+    assert rc == F.RT_ERR_STACK_DEPTH and "64" in F.hip.rt_last_error().decode()
+    d, keep = chain_desc(64)  # 63: accepted by validation (then RT_ERR_HIP without a GPU, RT_OK with one)
+    rc = F.hip.rt_scene_create(0, C.byref(d), C.byref(out))
+    assert rc in (F.RT_OK, F.RT_ERR_HIP)
+    if rc == F.RT_OK:
+        F.hip.rt_scene_destroy(out)
+    # an orphan node (not reachable from the root) is refused
+    d, keep = chain_desc(10)
+    right = np.ctypeslib.as_array(d.node_right, shape=(d.n_nodes,)).copy()
+    right[3] = 0x80000000 | 9  # node 3 ends the chain early: nodes 4..8 and leaves 4..8 hang in the air
+    d.node_right = right.ctypes.data_as(C.POINTER(C.c_uint32))
+    rc = F.hip.rt_scene_create(0, C.byref(d), C.byref(out))
+    assert rc == F.RT_ERR_BAD_ARG and "reachable" in F.hip.rt_last_error().decode()
+
+
+def test_render_multi_checks_its_request_before_building_anything():
+    """a 1-pixel-wide image, an oversized image or a sample-index overflow must be refused up front,
+    not after G scene uploads (so it is refused even without a GPU)."""
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    hs = R.HostScene("cornell_box", 1.0)
+    for kw, what in (({"width": 1}, "2x2"), ({"width": 70000, "height": 70000}, "too large"),
+                     ({"sample_offset": 0xFFFFFFF0}, "32 bits")):
+        with pytest.raises(F.RtError, match=what) as e:
+            R.render_multi(hs, [0], kw.get("width", 8), kw.get("height", 8), 32, 5, sample_offset=kw.get("sample_offset", 0))
+        assert e.value.code == F.RT_ERR_BAD_ARG
+
 
 def test_host_errors_are_reported_not_thrown():
     import raytracer_amd as R
@@ -140,3 +190,41 @@ def test_no_gpu_means_an_error_not_a_cpu_fallback():
     p = subprocess.run([R.CLI, "-s", "5", "-i", "16", "--samples-per-pixel", "1", "-o", "/tmp/never.png"],
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 1 and p.stderr.startswith("error:") and "Created image!" not in p.stdout
+
+
+def test_texture_file_side_channel(tmp_path):
+    """a29, Texture::new_image (texture.rs:25-31): the host layer decodes no JPEG; the image arrives as RGB8 in memory
+    or as a binary PPM through rth_texture_from_rgb8_file.  Round trip of the shipped earth texture, and the two
+    ways the reference would panic (missing file, scenes.rs:126; a scene that needs texels and gets none) come
+    back as RT_ERR_BAD_ARG through the library."""
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    tex = R.load_earthmap()
+    assert tex.shape == (512, 1024, 3) and tex.dtype == np.uint8
+    path = tmp_path / "earthmap.ppm"
+    R.write_earthmap_ppm(str(path))
+    back = R.texture_from_file(str(path))
+    assert np.array_equal(back, tex)
+    # comments in the header are legal PPM
+    raw = path.read_bytes()
+    (tmp_path / "c.ppm").write_bytes(b"P6\n# earth\n1024 512\n# maxval\n255\n" + raw[raw.index(b"255\n") + 4:])
+    assert np.array_equal(R.texture_from_file(str(tmp_path / "c.ppm")), tex)
+    with pytest.raises(F.RtError, match="cannot open") as e:
+        R.texture_from_file(str(tmp_path / "missing.ppm"))
+    assert e.value.code == F.RT_ERR_BAD_ARG
+    (tmp_path / "short.ppm").write_bytes(raw[:1000])
+    with pytest.raises(F.RtError, match="not a complete binary PPM"):
+        R.texture_from_file(str(tmp_path / "short.ppm"))
+    (tmp_path / "jpeg.ppm").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    with pytest.raises(F.RtError, match="not a complete binary PPM"):
+        R.texture_from_file(str(tmp_path / "jpeg.ppm"))
+    for sid in (2, 4, 8, 11):  # every scene that calls Texture::new_image
+        o = F.RthSceneOpts()
+        o.scene_id, o.rotate_bbox, o.aspect_ratio, o.scene_seed, o.bvh_seed = sid, -1, 1.5, 5, 7
+        h = C.c_void_p()
+        assert F.host.rth_scene_build(C.byref(o), C.byref(h)) == F.RT_ERR_BAD_ARG
+        assert b"texels" in F.host.rth_last_error()
+    # the same scene built from the file's texels equals the one built from the shipped decode
+    a = R.HostScene(2, 1.5, texels=back)
+    b = R.HostScene(2, 1.5)
+    assert a.desc.n_texel_bytes == b.desc.n_texel_bytes == tex.size

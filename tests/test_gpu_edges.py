@@ -288,3 +288,75 @@ def test_empty_world_and_ragged_tiny_images(size):
     for kw in ({}, {"f64": True}, {"fast": True}):
         ids = ds.primary_hits(w, h, **kw)[0]
         assert (ids == 0xFFFFFFFF).all()
+
+
+def test_deepest_accepted_tree_renders_and_a_deeper_one_is_refused():
+    """RT_MAX_BVH_HEIGHT: the reference-order kernels keep 4 B per tree level and lane in LDS.  A chain tree of
+    exactly that height renders on every kernel family that walks it (f32 reference-order walk, f64 audit,
+    and whatever the fast path picks) and hits the same spheres; one level more is RT_ERR_STACK_DEPTH at
+    rt_scene_create, not an opaque launch failure later."""
+    import types
+    import raytracer_amd as R
+    from desc_util import chain_desc
+    from raytracer_amd import _ffi as F
+    view = R.HostScene(5, 1.5)  # camera (13,2,3) -> origin sees the row of spheres
+    d, keep = chain_desc(64)   # 63 nodes on the root-to-leaf path: the limit
+    ds = R.DeviceScene(types.SimpleNamespace(desc=d, camera=view.camera), 0)
+    w, h = 96, 64
+    ids = {}
+    for tag, kw in (("f32", {}), ("f64", {"f64": True}), ("fast", {"fast": True})):
+        ids[tag] = ds.primary_hits(w, h, **kw)[0]
+    assert np.array_equal(ids["f32"], ids["f64"]) and np.array_equal(ids["f32"], ids["fast"])
+    assert len(np.unique(ids["f32"])) > 20  # most of the 64 spheres are seen
+    a, sa = ds.render(w, h, 4, 6, seed=2, stats=True, force_bvh=True)
+    b, sb = ds.render(w, h, 4, 6, seed=2, stats=True, f64=True)
+    c, sc = ds.render(w, h, 4, 6, seed=2, stats=True)
+    assert sa["nodes_visited"] > 0 and sa["rays"] == sc["rays"]
+    assert abs(float(a.sum()) / float(b.sum()) - 1.0) < 1e-3
+    np.testing.assert_allclose(a, c, rtol=1e-4, atol=1e-5)
+    d2, keep2 = chain_desc(65)  # 64 nodes deep
+    with pytest.raises(F.RtError) as e:
+        R.DeviceScene(types.SimpleNamespace(desc=d2, camera=view.camera), 0)
+    assert e.value.code == F.RT_ERR_STACK_DEPTH
+
+
+def test_f32_drops_the_samples_that_poison_f64_pixels():
+    """Q9/Q10: a light-sampled direction with pdf 0 makes the sample NaN; the reference (and the f64
+    audit kernel) add it to the pixel, which quantises to 0 (main.rs:59-61, 165); the f32 product kernels drop and
+    count it (rt.h, rt_render_device).  Scene: simple_light with its second light re-tagged RT_LIGHT_OTHER
+    (random() = (1,0,0), pdf_value = 0: hittable.rs:498, 513), which makes such samples common.  At equal seed the
+    two kernels follow the same paths almost everywhere, so the f32 kernel must report dropped samples, and the
+    pixels the f64 kernel poisoned must be (nearly all) pixels where f32 dropped something: checked through the
+    per-pixel deficit of the f32 image against a render that cannot drop (depth-limited sums are positive)."""
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    hs = R.HostScene(3, 1.5)
+    d = F.RtSceneDesc()
+    C.memmove(C.byref(d), C.byref(hs.desc), C.sizeof(d))
+    tags = (C.c_uint8 * 2)(hs.desc.light_tag[0], 1)
+    d.light_tag = C.cast(tags, type(d.light_tag))
+
+    class Mutated(R.DeviceScene):
+        def __init__(self):
+            self.host = hs
+            self.device = 0
+            h = C.c_void_p()
+            F.check_hip(F.hip.rt_scene_create(0, C.byref(d), C.byref(h)))
+            self._h = h
+
+    ds = Mutated()
+    w, h, spp = 48, 32, 16
+    f32, s32 = ds.render(w, h, spp, 3, seed=2, stats=True)
+    f64, s64 = ds.render(w, h, spp, 3, seed=2, stats=True, f64=True)
+    assert np.isfinite(f32).all()                       # f32: never poisoned
+    bad64 = ~np.isfinite(f64).all(axis=-1)              # f64: pixels the reference would paint black
+    assert s32["nonfinite_samples"] > 0 and s64["nonfinite_samples"] > 0
+    assert bad64.sum() > 0
+    # the f64 kernel counts poisoned SAMPLES too.  At equal seed the f32 kernel sees a SUBSET of its events: it also
+    # stops a path whose throughput has reached exactly 0 (a light-sampled direction below the horizon:
+    # scattering_pdf 0), and the reference walks such a path on, where a later vertex with pdf_value 0 turns the
+    # 0 into 0 * inf = NaN.  Those samples contribute 0 in f32 and poison the pixel in the reference.
+    assert 0.3 * s64["nonfinite_samples"] <= s32["nonfinite_samples"] <= 1.02 * s64["nonfinite_samples"] + 4
+    # tone-mapped: the reference's pixel is 0 where poisoned, the f32 one is a finite colour
+    u8_64 = R.tonemap(np.nan_to_num(f64, nan=np.nan).astype(np.float32), spp)
+    assert (u8_64[bad64] == 0).all()

@@ -92,31 +92,49 @@ def _psnr(a, b):
     return 10 * np.log10(1.0 / mse) if mse > 0 else np.inf
 
 
+def _chunk_means(render_chunk, spp, chunks, clip):
+    """Per-pixel mean and standard error of the mean from `chunks` independent renders of spp/chunks samples."""
+    per = spp // chunks
+    ms = []
+    for c in range(chunks):
+        m = render_chunk(c * per, per).astype(np.float64) / per
+        m = np.where(np.isfinite(m), m, 0.0)
+        ms.append(np.clip(m, 0, clip) if clip else m)
+    ms = np.stack(ms)
+    return ms.mean(axis=0), ms.std(axis=0, ddof=1) / np.sqrt(chunks)
+
+
 @pytest.mark.parametrize("name", ["random_scene", "simple_light", "cornell_box", "earth", "small_scene", "final_scene",
                                   "bvh_stress", "perlin_spheres"])
 def test_render_f32_within_monte_carlo_noise(name, earthmap):
-    """f32 production kernel vs oracle, different seeds, matched spp: the difference of two
-    independent estimates must look like noise of the measured per-pixel variance."""
+    """f32 production kernel vs oracle, different seeds, matched spp (main.rs:160-167's estimator): the
+    difference of two independent estimates must look like noise of the MEASURED per-pixel variance —
+    per pixel channel, z = |gpu - oracle| / sqrt(se_gpu^2 + se_oracle^2) with the standard errors taken from
+    the spread of 16 chunk means: >= 98.5 % inside 3 sigma (a t-distribution with 15 degrees of freedom has
+    99.1 % there), no pixel beyond 8 sigma except in the heavy-tailed scenes, and the image means within
+    4 standard errors of the difference of the means."""
     hs, ds, os_, h, depth = _pair(name, earthmap)
-    spp = 256
-    g, gst = ds.render(W, h, spp, depth, seed=21)
-    o1, _, _ = os_.render(W, h, spp, depth, seed=22)
-    o2, _, _ = os_.render(W, h, spp, depth, seed=23)
-    g = g.astype(np.float64) / spp
-    o1 /= spp
-    o2 /= spp
-    fin = np.isfinite(g) & np.isfinite(o1) & np.isfinite(o2)
-    # oracle-vs-oracle difference estimates the noise floor; gpu-vs-oracle must not exceed it by much
-    d_ref = np.sqrt(np.mean((np.clip(o1, 0, 1) - np.clip(o2, 0, 1))[fin] ** 2))
-    d_gpu = np.sqrt(np.mean((np.clip(g, 0, 1) - np.clip(o1, 0, 1))[fin] ** 2))
-    if name in ("final_scene", "bvh_stress"):  # heavy-tailed estimators (fireflies of 1e20 and more): compare clipped means
-        mean_ratio = np.clip(g, 0, 1)[fin].mean() / np.clip(o1, 0, 1)[fin].mean()
-    else:
-        mean_ratio = g[fin].mean() / o1[fin].mean()
-    print(f"{name}: rmse gpu-vs-oracle {d_gpu:.4g}, oracle-vs-oracle {d_ref:.4g}, mean ratio {mean_ratio:.4f}, "
-          f"nonfinite samples {gst['nonfinite_samples']}")
-    assert d_gpu <= 1.25 * d_ref + 1e-4
-    assert abs(mean_ratio - 1.0) <= 0.02
+    spp, chunks = 512, 16
+    # final_scene / bvh_stress: the reference's estimator has fireflies of 1e20 and more (fog gains energy per
+    # scatter; glass next to the sky): compare chunk means clipped to the displayable range
+    clip = 4.0 if name in ("final_scene", "bvh_stress") else 0.0
+    g, sg = _chunk_means(lambda off, n: ds.render(W, h, n, depth, seed=21, sample_offset=off)[0], spp, chunks, clip)
+    o, so = _chunk_means(lambda off, n: os_.render(W, h, n, depth, seed=22, sample_offset=off)[0], spp, chunks, clip)
+    sig = np.sqrt(sg * sg + so * so)
+    # pixels without real spread in either estimate (background, saturated emitters: every sample the same number
+    # up to rounding) must agree outright; the z-score is for the others
+    lit = sig > 1e-6 * (np.abs(g) + np.abs(o)) + 1e-9
+    z = np.abs(g - o)[lit] / sig[lit]
+    flat = ~lit
+    assert np.allclose(g[flat], o[flat], rtol=1e-4, atol=1e-6), f"{name}: flat pixels differ by {np.abs(g - o)[flat].max()}"
+    mean_g, mean_o = g.mean(), o.mean()
+    se_mean = np.sqrt((sg ** 2).sum() + (so ** 2).sum()) / g.size
+    print(f"{name}: within 3 sigma {np.mean(z <= 3):.4f}, max z {z.max():.2f}, mean ratio {mean_g / mean_o:.5f} "
+          f"(+- {se_mean / mean_o:.5f})")
+    assert np.mean(z <= 3.0) >= 0.985, f"{name}: only {np.mean(z <= 3):.4f} of pixel channels inside 3 sigma"
+    if not clip:
+        assert z.max() <= 8.0, f"{name}: a pixel channel is {z.max():.1f} sigma off"
+    assert abs(mean_g - mean_o) <= 4.0 * se_mean, f"{name}: means {mean_g} vs {mean_o}, se {se_mean}"
 
 
 @pytest.mark.parametrize("name", ["cornell_box", "small_scene", "two_spheres", "cube_scene"])
@@ -200,7 +218,7 @@ def test_f32_tracks_f64_audit_at_equal_seed(name, earthmap):
         a, sa = ds.render(W, h, 64, d, seed=21, stats=True)
         b, sb = ds.render(W, h, 64, d, seed=21, stats=True, f64=True)
         ta, tb = float(a[np.isfinite(a)].sum()), float(b[np.isfinite(b)].sum())
-        assert abs(ta / tb - 1.0) <= 0.01, (name, d, ta, tb)
+        assert abs(ta / tb - 1.0) <= 2e-3, (name, d, ta, tb)
         # (work counters are not compared: the f32 kernel stops a path at zero throughput, the audit kernel
         # walks it to the end like the reference)
 
