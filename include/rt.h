@@ -27,6 +27,7 @@ extern "C" {
 
 #define RT_ABI_VERSION 1u
 #define RT_MAX_BVH_HEIGHT 63u       /* nodes on a root-to-leaf path: 4 B per level and lane of LDS, 64 KiB per workgroup */
+#define RT_NOALLOC_MAX_LAUNCHES 63u /* rt_render_device_noalloc: kernel launches per call (256 B of static scratch each) */
 
 typedef struct rt_scene rt_scene; /* opaque: one per (scene, device) */
 
@@ -248,6 +249,19 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* par
  * reference-precision leg (the reference computes in f64 throughout, alias.rs:4-7).        */
 int rt_render_f64_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
                          double* accum_rgb_device, int accumulate, void* stream, rt_stats* stats);
+
+/* No counterpart in the reference.  For callers that cannot allocate: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  Same contract and same kernels as
+ * rt_render_device, but the kernels' scratch (per launch: the work counters and the persistent
+ * kernels' unit counter) lives in a file-scope __device__ array of RT_NOALLOC_MAX_LAUNCHES x 256 B =
+ * 15.75 KiB that every GPU the library runs on holds until the process ends; the call itself makes no
+ * hipMalloc / hipFree or other allocating call (memsets, launches, two event records; with stats != NULL
+ * also one stream synchronise and a <= 16 KiB copy-back, so pass NULL under capture).  A call that needs
+ * more than RT_NOALLOC_MAX_LAUNCHES launches (spp / spp_per_launch, default 4096 per launch) is refused
+ * with RT_ERR_BAD_ARG.  Every call on one GPU shares that GPU's array (whatever the scene): calls that
+ * overlap on one GPU race; the call zeroes what it uses.                                          */
+int rt_render_device_noalloc(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+                             float* accum_rgb_device, int accumulate, void* stream, rt_stats* stats);
 
 /* Replaces: the same closure (main.rs:154-167) with rayon's worker pool (main.rs:157) lifted from
  * cores to the GPUs of one node, in ONE process: one host thread per entry of `devices` builds its

@@ -189,13 +189,13 @@ class DeviceScene:
 
     def render_device(self, accum_ptr, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0,
                       accumulate=False, stream=None, want_stats=True, stats=False, camera=None, force_bvh=False,
-                      f64=False):
+                      f64=False, noalloc=False):
         """Same, into DEVICE memory (accum_ptr = raw device address of a float32 [h][w][3] buffer; float64 with
-        f64=True: rt_render_f64_device)."""
+        f64=True: rt_render_f64_device).  noalloc=True: rt_render_device_noalloc (static scratch, no allocation)."""
         p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh)
         st = F.RtStats()
         cam = camera if camera is not None else self.host.camera
-        fn = F.hip.rt_render_f64_device if f64 else F.hip.rt_render_device
+        fn = F.hip.rt_render_f64_device if f64 else (F.hip.rt_render_device_noalloc if noalloc else F.hip.rt_render_device)
         F.check_hip(fn(self._h, C.byref(cam), C.byref(p), C.c_void_p(accum_ptr), 1 if accumulate else 0,
                        C.c_void_p(stream or 0), C.byref(st) if want_stats else None))
         return st.as_dict() if want_stats else None

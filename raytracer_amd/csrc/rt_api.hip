@@ -493,8 +493,41 @@ constexpr uint32_t TARGET_WAVES = 96u * 1024u;
 
 }  // namespace
 
+// ---- scratch of rt_render_device_noalloc (rt.h) ----------------------------------------------------------------
+// One 256-byte slot per kernel launch of a call (a DeviceStats block: the work counters and the persistent
+// kernels' unit counter), in a file-scope device array instead of memory the library allocates.  Every GPU the
+// library runs on holds its own copy of the array at its own address; g_scratch_ptr[device] is that address
+// (hipGetSymbolAddress, once per device, with that device current: noalloc_scratch_for below).  Host code must
+// never pass the array's NAME to a kernel or a memset: it is a host-side stand-in, not a device address.
+constexpr size_t NOALLOC_SLOT_BYTES = 256;
+static_assert(sizeof(DeviceStats) <= NOALLOC_SLOT_BYTES, "one DeviceStats block per scratch slot");
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SLOT_BYTES * RT_NOALLOC_MAX_LAUNCHES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[MAX_DEVICES] = {};
+
+// Device address of `scratch` on `device` (which must be the current device).
+hipError_t noalloc_scratch_for(int device, unsigned char** out) {
+  *out = nullptr;
+  if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    unsigned char* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = ptr;
+  }
+  *out = g_scratch_ptr[device];
+  return hipSuccess;
+}
+}  // namespace
+
 struct rt_scene {
   int device = 0;
+  unsigned char* static_scratch = nullptr;  // this device's copy of `scratch` (never freed: it is not ours to free)
   uint32_t stack_depth = 1;
   uint32_t n_nodes = 0;
   bool boxes_conservative = false;               // leaf-list / ordered walks allowed ...
@@ -725,6 +758,10 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
 
   rt_scene* s = new rt_scene;
   s->device = device;
+  if (hipError_t e0 = noalloc_scratch_for(device, &s->static_scratch); e0 != hipSuccess) {
+    delete s;
+    return fail(RT_ERR_HIP, "rt_scene_create: hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e0));
+  }
   s->stack_depth = std::max(tree_height, 1u);
   s->n_nodes = d->n_nodes;
   hipError_t e;
@@ -870,7 +907,6 @@ int check_params(const rt_params* p, const char* who) {
 // every launch uses it, its unit counter is re-zeroed between launches.  n_blocks > 1 (rt_render_device_noalloc: the
 // file-scope scratch, 256-byte slots): launch i uses slot i, all slots are zeroed by one memset up front and the
 // counters are summed on the host.
-constexpr size_t NOALLOC_SLOT_BYTES = 256;
 template <typename R>
 int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d_accum, int accumulate,
                      hipStream_t stream, rt_stats* stats, unsigned char* blocks = nullptr, uint32_t n_blocks = 1) {
@@ -920,7 +956,8 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
       HIP_TRY(hipMemcpyAsync(&hs, s->dstats, sizeof(hs), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
     } else {
-      alignas(16) unsigned char image[NOALLOC_SLOT_BYTES * 64];
+      static_assert(NOALLOC_SLOT_BYTES * RT_NOALLOC_MAX_LAUNCHES <= 64 * 1024, "the slot image is read back through the stack");
+      alignas(16) unsigned char image[NOALLOC_SLOT_BYTES * RT_NOALLOC_MAX_LAUNCHES];
       if (launches) HIP_TRY(hipMemcpyAsync(image, blocks, (size_t)launches * NOALLOC_SLOT_BYTES, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
       for (uint32_t i = 0; i < launches; ++i) {
@@ -1030,6 +1067,18 @@ int rt_render_f64_device(rt_scene* s, const rt_camera* cam, const rt_params* p, 
                          void* stream, rt_stats* stats) {
   return render_on_device<double>(s, cam, p, d_accum, accumulate, (hipStream_t)stream, stats);
 }
+// rt_render_device without any allocation behind it: the launches' DeviceStats blocks (work counters + the
+// persistent kernels' unit counter) live in the file-scope `scratch` array, one 256-byte slot per launch, addressed
+// through the per-device pointer hipGetSymbolAddress returned (never through the array's name).  No hipMalloc /
+// hipFree here or below: memsets, kernel launches, event records, and (only if stats != NULL) one small copy-back.
+int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, const rt_params* p, float* d_accum, int accumulate,
+                             void* stream, rt_stats* stats) {
+  if (!s) return fail(RT_ERR_BAD_ARG, "rt_render_device_noalloc: null scene");
+  if (!s->static_scratch) return fail(RT_ERR_HIP, "rt_render_device_noalloc: the scratch array has no address on device %d", s->device);
+  return render_on_device<float>(s, cam, p, d_accum, accumulate, (hipStream_t)stream, stats, s->static_scratch,
+                                 RT_NOALLOC_MAX_LAUNCHES);
+}
+
 // One host thread per device (rayon's "shared immutable scene, independent workers" model,
 // main.rs:157-169, lifted from cores to GPUs): device g renders samples [g*spp/G, (g+1)*spp/G) of
 // every pixel into its own HBM accumulator; the shards are then summed on devices[0].  Every peer
