@@ -265,7 +265,7 @@ RT_DEV bool complex_t(const SceneView<R>& sc, uint32_t idx, const RayT<R>& r, R 
   t1 = rmax(t1, R(0));
   R ray_length = length(dm);
   R distance_inside_boundary = (t2 - t1) * ray_length;
-  R hit_distance = neg_inv_density * rlog(rng.template keyed<R>(cx.object));
+  R hit_distance = neg_inv_density * rng.template keyed_log<R>(cx.object);
   if (hit_distance > distance_inside_boundary) return false;
   t_out = medium_exit_t(t1, hit_distance, ray_length);
   return true;
@@ -362,7 +362,7 @@ RT_DEV bool leaf_t_unified(const SceneView<float>& sc, uint32_t ref, const RayT<
   if (t1 >= t2) return false;
   t1 = rmax(t1, 0.0f);
   const float ray_length = length(r.d);  // rigid maps keep |d|
-  const float hit_distance = neg_inv_density * rlog(rng.template keyed<float>(object));
+  const float hit_distance = neg_inv_density * rng.template keyed_log<float>(object);
   if (hit_distance > (t2 - t1) * ray_length) return false;
   t_out = medium_exit_t(t1, hit_distance, ray_length);
   return true;
@@ -611,7 +611,7 @@ RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, LinMasks masks,
       if (!(t1 < t2)) return false;
       t1 = rmax(t1, 0.0f);
       const float ray_length = length(r.d);  // rigid maps keep |d|
-      const float hit_distance = rec[LIN_NID] * rlog(rng.keyed<float>(__float_as_uint(rec[LIN_OBJECT])));
+      const float hit_distance = rec[LIN_NID] * rng.keyed_log<float>(__float_as_uint(rec[LIN_OBJECT]));
       if (hit_distance > (t2 - t1) * ray_length) return false;
       t = medium_exit_t(t1, hit_distance, ray_length);
       return true;

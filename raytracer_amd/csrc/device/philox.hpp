@@ -102,6 +102,21 @@ struct Rng {
   template <typename R> RT_DEV R keyed(uint32_t object_id) const {
     return u01<R>(philox_path(pixel, sample, slot, 0x80000000u | object_id, k0, k1).x);
   }
+  // ln of that draw (hittable.rs:342: `ln(rand::random())`), from all 32 bits of the word in BOTH precisions.  u01<float>
+  // keeps 24 bits, and near u = 1 (a short free path) ln(u) ~ -(1 - u) then carries a relative error of 2^-24 / (1 - u):
+  // seen as 5e-4 on the primary t of final_scene's fog.  Here u < 1/2 goes through ln(x 2^-32) and u >= 1/2 through
+  // log1p(-(2^32 - x) 2^-32): in either branch the argument has full relative precision, so ln(u) agrees with the f64
+  // kernel's (and the oracle's) to f32 rounding.  x = 0 gives -inf (no scatter) in both.
+  template <typename R> RT_DEV R keyed_log(uint32_t object_id) const {
+    const uint32_t x = philox_path(pixel, sample, slot, 0x80000000u | object_id, k0, k1).x;
+    if constexpr (sizeof(R) == 8) {
+      return log(u01<double>(x));
+    } else {
+      const float lo = logf((float)x * (1.0f / 4294967296.0f));
+      const float hi = log1pf(-((float)(0u - x) * (1.0f / 4294967296.0f)));
+      return x < 0x80000000u ? lo : hi;
+    }
+  }
   template <typename R> RT_DEV R next() { return u01<R>(next_u32()); }
   template <typename R> RT_DEV R range(R lo, R hi) { return lo + (hi - lo) * next<R>(); }
   RT_DEV uint32_t below(uint32_t n) { return __umulhi(next_u32(), n); }
