@@ -204,13 +204,23 @@ void rt_scene_destroy(rt_scene* scene);
 /* Replaces: one `world.hit(r, 0.001, inf)` per pixel (main.rs:77) for the deterministic
  * primary ray through the pixel centre (no jitter, no lens offset, ray.time = time), with
  * draw stream (pixel, sample 0, slot 1).  Outputs are host arrays [h][w]...; prim_id is the
- * world-level object id or RT_REF_NONE; uv / front_face may be null.                     */
+ * world-level object id or RT_REF_NONE; uv / front_face may be null.
+ * rt_primary_hits (f32) answers with the f32 product walk — the leaf arithmetic rt_render runs — on the pixel-centre
+ * ray formed in f64 and rounded once, and AUDITS every decision of that walk with a forward error bound built from
+ * the inputs' own f64 -> f32 rounding deltas (device/audit.hpp).  A pixel where some decision (hit or miss, which
+ * root, which candidate is nearer, a cube's face pick) sits inside its bound, or whose t may be off by more than
+ * 5e-6 relative, is re-decided by the f64 audit kernel; rt_primary_redecided() tells how many pixels of the last
+ * call that was (typically 1-3 %: silhouettes, grazing hits, exact ties such as the Cornell box's image diagonal).
+ * Result: ids and front_face equal to the f64 reference's, t within 1e-5 relative, on every pixel.           */
 int rt_primary_hits(rt_scene* scene, const rt_camera* cam, uint32_t width, uint32_t height,
                     uint64_t seed, double time, uint32_t* prim_id, float* t, float* normal /*[.][3]*/,
                     float* uv /*[.][2]*/, uint8_t* front_face);
 int rt_primary_hits_f64(rt_scene* scene, const rt_camera* cam, uint32_t width, uint32_t height,
                         uint64_t seed, double time, uint32_t* prim_id, double* t, double* normal,
                         double* uv, uint8_t* front_face);
+
+/* Pixels of the last rt_primary_hits / rt_primary_hits_fast call on this scene that the audit handed to the f64 kernel. */
+uint64_t rt_primary_redecided(const rt_scene* scene);
 
 /* The same query answered by the walk rt_render uses for this scene (the leaf list, or the ordered walk of
  * the library's own SAH tree when every box is proven conservative; else the reference-order walk):

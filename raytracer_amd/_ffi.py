@@ -96,7 +96,7 @@ class RthRenderOpts(C.Structure):
 
 # every symbol include/rt.h and include/rt_host.h declare (tests check the export lists against the headers)
 RT_SYMBOLS = [
-    "rt_scene_create", "rt_scene_destroy", "rt_primary_hits", "rt_primary_hits_f64", "rt_primary_hits_fast", "rt_render",
+    "rt_scene_create", "rt_scene_destroy", "rt_primary_hits", "rt_primary_hits_f64", "rt_primary_hits_fast", "rt_primary_redecided", "rt_render",
     "rt_render_f64", "rt_render_device", "rt_render_f64_device", "rt_render_device_noalloc", "rt_render_multi", "rt_debug_build_tree", "rt_tonemap", "rt_tonemap_device", "rt_kat_sphere_uv", "rt_kat_rotate",
     "rt_kat_philox", "rt_device_count", "rt_abi_version", "rt_last_error",
 ]
@@ -131,6 +131,8 @@ hip.rt_primary_hits.argtypes = [_p, C.POINTER(RtCamera), C.c_uint32, C.c_uint32,
                                 _p, _p, _p, _p, _p]
 hip.rt_primary_hits_f64.argtypes = hip.rt_primary_hits.argtypes
 hip.rt_primary_hits_fast.argtypes = hip.rt_primary_hits.argtypes
+hip.rt_primary_redecided.argtypes = [_p]
+hip.rt_primary_redecided.restype = C.c_uint64
 hip.rt_render.argtypes = [_p, C.POINTER(RtCamera), C.POINTER(RtParams), _p, C.POINTER(RtStats)]
 hip.rt_render_f64.argtypes = hip.rt_render.argtypes
 hip.rt_render_device.argtypes = [_p, C.POINTER(RtCamera), C.POINTER(RtParams), _p, C.c_int, _p, C.POINTER(RtStats)]

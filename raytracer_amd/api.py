@@ -166,6 +166,7 @@ class DeviceScene:
         cam = camera if camera is not None else self.host.camera
         F.check_hip(fn(self._h, C.byref(cam), width, height, seed, time, _ptr(ids), _ptr(t), _ptr(nrm), _ptr(uv),
                        _ptr(ff)))
+        self.redecided = int(F.hip.rt_primary_redecided(self._h))  # f32: pixels the audit handed to the f64 kernel
         return ids, t, nrm, uv, ff
 
     def _params(self, width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh=False):

@@ -10,7 +10,7 @@
 // apart in sample index but stay busy (the recursion of ray_color becomes
 // throughput/radiance registers).  Per-lane BVH stack lives in LDS, column-major by lane.
 #pragma once
-#include "intersect.hpp"
+#include "audit.hpp"
 
 namespace rt {
 
@@ -1275,6 +1275,136 @@ __global__ void __launch_bounds__(BLOCK) primary_kernel(SceneView<R> sc, CameraV
   }
   if (front_face) front_face[pixel] = h.front_face ? 1 : 0;
 }
+
+// rt_primary_hits / rt_primary_hits_fast in f32: the product walk's answer, plus the error-tracked audit of audit.hpp.
+// The ray is the deterministic pixel-centre ray formed in f64 (the reference's expression, cam.rs:68) and rounded
+// ONCE to f32, so that its rounding delta is half an ulp per component (the render kernels form their jittered rays
+// in f32: their direction error is set by the 24-bit jitter anyway).  unsure_out[pixel] = 1 asks the host to have the
+// pixel re-decided by primary_fix_kernel (f64 TU).
+template <int TRAV>
+__global__ void __launch_bounds__(BLOCK) primary_f32_kernel(SceneView<float> sc, SceneView<double> sc64, CameraView<double> cam64,
+                                                            uint32_t width, uint32_t height, uint64_t seed, double time,
+                                                            uint32_t* __restrict__ prim_id, float* __restrict__ t_out,
+                                                            float* __restrict__ normal, float* __restrict__ uv,
+                                                            uint8_t* __restrict__ front_face, uint8_t* __restrict__ unsure_out,
+                                                            uint32_t stack_depth) {
+  using R = float;
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  uint32_t px, py;
+  tile_pixel(width, px, py);
+  if (px >= width || py >= height) return;
+  const uint32_t pixel = py * width + px;
+  RayT<double> r64;
+  {
+    const double u = ((double)px + 0.5) / (double)(width - 1);
+    const double v = ((double)(height - py - 1) + 0.5) / (double)(height - 1);
+    r64.o = cam64.origin;
+    r64.d = cam64.lower_left + u * cam64.horizontal + v * cam64.vertical - cam64.origin;
+    r64.time = time;
+  }
+  RayT<R> ray;
+  ray.o = Vec3<R>((R)r64.o.x, (R)r64.o.y, (R)r64.o.z);
+  ray.d = Vec3<R>((R)r64.d.x, (R)r64.d.y, (R)r64.d.z);
+  ray.time = (R)time;
+  Rng rng;
+  rng.init(seed, pixel, 0);
+  rng.begin(1);
+  Cnt<false> cnt;
+  cnt.clear();
+  R t;
+  uint32_t best;
+  if constexpr (TRAV == TRAV_ORDERED) {
+    OrderedWalk walk;
+    bool more = walk.start(sc, ray);
+    while (more)
+      more = walk.step(sc, ray, R(0.001), rng, stack, reinterpret_cast<uint16_t*>(lds_stack + stack_depth * BLOCK) + threadIdx.x,
+                       (uint32_t)BLOCK, cnt);
+    t = walk.closest;
+    best = walk.best;
+  } else if constexpr (TRAV == TRAV_LINEAR) {
+    uint32_t k;
+    traverse_linear<false, true>(reinterpret_cast<const float*>(sc.linear_rec), sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, k, cnt);
+    best = k == REF_NONE ? REF_NONE : sc.linear_rec[k * LIN_DWORDS + LIN_REF];
+  } else {
+    traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+  }
+  // the audit: same walk order as the reference, same leaf arithmetic, with error bounds
+  R ta, e_t;
+  uint32_t besta;
+  uint32_t unsure = traverse_audit(sc, sc64, ray, r64, R(0.001), rng, stack, (uint32_t)BLOCK, ta, besta, e_t);
+  if (besta != best || !(ta == t)) unsure |= AUD_ACCURACY;  // (never observed: the walks share their leaf code)
+  HitRec<R> h;
+  h.object = REF_NONE;
+  h.normal = Vec3<R>(0, 0, 0);
+  h.uv.x = h.uv.y = R(0);
+  h.front_face = false;
+  if (best != REF_NONE) {
+    make_hit_record(sc, best, ray, t, true, h);
+    if (audit_record_unsure(sc, sc64, best, ray, r64, t, e_t)) unsure |= AUD_CUBE;
+  }
+  prim_id[pixel] = h.object;
+  t_out[pixel] = t;
+  normal[3ull * pixel + 0] = h.normal.x;
+  normal[3ull * pixel + 1] = h.normal.y;
+  normal[3ull * pixel + 2] = h.normal.z;
+  if (uv) {
+    uv[2ull * pixel + 0] = h.uv.x;
+    uv[2ull * pixel + 1] = h.uv.y;
+  }
+  if (front_face) front_face[pixel] = h.front_face ? 1 : 0;
+  unsure_out[pixel] = (uint8_t)unsure;  // AUD_* mask: non-zero = re-decide
+}
+
+#ifdef RT_DEFINE_F64_FIX
+// The pixels primary_f32_kernel marked: world.hit() in f64 exactly as primary_kernel<double> (and the oracle) evaluates
+// it, written into the f32 outputs.  Lives in the f64 translation unit (contraction off): an exact tie — the Cornell
+// box's image diagonal runs along the seam of two walls — must break the way the reference's arithmetic breaks it.
+__global__ void __launch_bounds__(BLOCK) primary_fix_kernel(SceneView<double> sc, CameraView<double> cam, uint32_t width,
+                                                            uint32_t height, uint64_t seed, double time,
+                                                            const uint8_t* __restrict__ unsure, uint32_t* __restrict__ prim_id,
+                                                            float* __restrict__ t_out, float* __restrict__ normal,
+                                                            float* __restrict__ uv, uint8_t* __restrict__ front_face) {
+  using R = double;
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  uint32_t px, py;
+  tile_pixel(width, px, py);
+  if (px >= width || py >= height) return;
+  const uint32_t pixel = py * width + px;
+  if (!unsure[pixel]) return;
+  R u = ((R)px + R(0.5)) / (R)(width - 1);
+  R v = ((R)(height - py - 1) + R(0.5)) / (R)(height - 1);
+  RayT<R> ray;
+  ray.o = cam.origin;
+  ray.d = primary_direction(cam, u, v);
+  ray.time = time;
+  Rng rng;
+  rng.init(seed, pixel, 0);
+  rng.begin(1);
+  Cnt<false> cnt;
+  cnt.clear();
+  R t;
+  uint32_t best;
+  traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+  HitRec<R> h;
+  h.object = REF_NONE;
+  h.normal = Vec3<R>(0, 0, 0);
+  h.uv.x = h.uv.y = R(0);
+  h.front_face = false;
+  if (best != REF_NONE) make_hit_record(sc, best, ray, t, true, h);
+  prim_id[pixel] = h.object;
+  t_out[pixel] = (float)t;
+  normal[3ull * pixel + 0] = (float)h.normal.x;
+  normal[3ull * pixel + 1] = (float)h.normal.y;
+  normal[3ull * pixel + 2] = (float)h.normal.z;
+  if (uv) {
+    uv[2ull * pixel + 0] = (float)h.uv.x;
+    uv[2ull * pixel + 1] = (float)h.uv.y;
+  }
+  if (front_face) front_face[pixel] = h.front_face ? 1 : 0;
+}
+#endif  // RT_DEFINE_F64_FIX
 
 #ifdef RT_DEFINE_COMMON
 // main.rs:167-168, 51-63

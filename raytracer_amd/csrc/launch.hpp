@@ -14,6 +14,7 @@ struct LaunchShape {
   uint32_t tiles;        // 16x16 pixel tiles = workgroups along grid.x
   uint32_t splits;       // sample splits along grid.y (atomic accumulation when > 1)
   uint32_t stack_depth;  // LDS traversal-stack entries per lane
+  uint32_t ref_stack_depth = 1;  // ... of the reference's tree (the audit walk of rt_primary_hits always walks that one)
   uint32_t refill_eighths = 2;  // ordered walk: see RenderArgs::refill_eighths
   uint32_t leaf_shift = 2;      // ordered walk: see RenderArgs::leaf_shift
   // leaf-list scenes, persistent kernel (render_persist_kernel): 0 = off
@@ -37,6 +38,15 @@ struct LaunchShape {
 RT_DECLARE_LAUNCHERS(f32, float)
 RT_DECLARE_LAUNCHERS(f64, double)
 
+// rt_primary_hits in f32: product walk + error-tracked audit (rt_f32.hip), then the f64 re-decision of the marked pixels
+// (rt_f64.hip, contraction off)
+hipError_t launch_primary_audited_f32(const SceneView<float>& sc, const SceneView<double>& sc64, const CameraView<double>& cam64,
+                                      uint32_t width, uint32_t height, uint64_t seed, double time, uint32_t* prim_id, float* t,
+                                      float* normal, float* uv, uint8_t* front_face, uint8_t* unsure, LaunchShape shape,
+                                      hipStream_t st);
+hipError_t launch_primary_fix_f64(const SceneView<double>& sc, const CameraView<double>& cam, uint32_t width, uint32_t height,
+                                  uint64_t seed, double time, const uint8_t* unsure, uint32_t* prim_id, float* t, float* normal,
+                                  float* uv, uint8_t* front_face, uint32_t ref_stack_depth, hipStream_t st);
 hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t* out, hipStream_t st);
 hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, hipStream_t st);
 hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, int path_stream, uint32_t* out,

@@ -1,4 +1,5 @@
 // Included by rt_f32.hip and rt_f64.hip with RT_SUFFIX / RT_REAL / RT_EARLY_EXIT defined.
+#include <algorithm>
 #include <cstdlib>
 
 #include "device/kernels.hpp"
@@ -123,6 +124,39 @@ hipError_t RT_CAT(launch_primary_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, cons
                      prim_id, t, normal, uv, front_face, shape.stack_depth);
   return hipGetLastError();
 }
+
+#if RT_HAS_LINEAR
+hipError_t launch_primary_audited_f32(const SceneView<float>& sc, const SceneView<double>& sc64, const CameraView<double>& cam64,
+                                      uint32_t width, uint32_t height, uint64_t seed, double time, uint32_t* prim_id, float* t,
+                                      float* normal, float* uv, uint8_t* front_face, uint8_t* unsure, LaunchShape shape,
+                                      hipStream_t st) {
+  dim3 grid(shape.tiles, 1, 1), block(BLOCK, 1, 1);
+  // the audit walks the reference's tree (4 B per level and lane); the ordered walk needs 6 B per level of its own tree
+  const size_t lds_ref = (size_t)shape.ref_stack_depth * BLOCK * sizeof(uint32_t);
+  const size_t lds_own = (size_t)shape.stack_depth * BLOCK * sizeof(uint32_t);
+  if (shape.trav == TRAV_ORDERED) {
+    hipLaunchKernelGGL((primary_f32_kernel<TRAV_ORDERED>), grid, block, std::max(lds_ref, lds_own + lds_own / 2), st, sc, sc64,
+                       cam64, width, height, seed, time, prim_id, t, normal, uv, front_face, unsure, shape.stack_depth);
+  } else if (shape.trav == TRAV_LINEAR) {
+    hipLaunchKernelGGL((primary_f32_kernel<TRAV_LINEAR>), grid, block, lds_ref, st, sc, sc64, cam64, width, height, seed, time,
+                       prim_id, t, normal, uv, front_face, unsure, shape.stack_depth);
+  } else {
+    hipLaunchKernelGGL((primary_f32_kernel<TRAV_REFERENCE>), grid, block, lds_ref, st, sc, sc64, cam64, width, height, seed,
+                       time, prim_id, t, normal, uv, front_face, unsure, shape.stack_depth);
+  }
+  return hipGetLastError();
+}
+#endif
+#ifdef RT_DEFINE_F64_FIX
+hipError_t launch_primary_fix_f64(const SceneView<double>& sc, const CameraView<double>& cam, uint32_t width, uint32_t height,
+                                  uint64_t seed, double time, const uint8_t* unsure, uint32_t* prim_id, float* t, float* normal,
+                                  float* uv, uint8_t* front_face, uint32_t ref_stack_depth, hipStream_t st) {
+  const uint32_t tiles = ((width + 15) / 16) * ((height + 15) / 16);
+  hipLaunchKernelGGL(primary_fix_kernel, dim3(tiles), dim3(BLOCK), (size_t)ref_stack_depth * BLOCK * sizeof(uint32_t), st, sc, cam,
+                     width, height, seed, time, unsure, prim_id, t, normal, uv, front_face);
+  return hipGetLastError();
+}
+#endif
 
 hipError_t RT_CAT(launch_kat_sphere_uv_, RT_SUFFIX)(uint32_t n, const double* p, double* uv, hipStream_t st) {
   hipLaunchKernelGGL((kat_sphere_uv_kernel<RT_REAL>), dim3((n + 63) / 64), dim3(64), 0, st, n, p, uv);

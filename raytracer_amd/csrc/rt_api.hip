@@ -534,6 +534,7 @@ struct rt_scene {
   double safe_t_lo = 0, safe_t_hi = 0;           // ... for cameras whose shutter lies in this window
   SceneSide<float> f32;
   SceneSide<double> f64;
+  uint64_t last_redecided = 0;  // rt_primary_redecided
   DeviceStats* dstats = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   ~rt_scene() {
@@ -1005,6 +1006,7 @@ int primary_to_host(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t h, u
                     uint32_t* prim_id, R* t, R* normal, R* uv, uint8_t* front_face, bool fast = false) {
   if (!s || !cam || !prim_id || !t || !normal) return fail(RT_ERR_BAD_ARG, "rt_primary_hits: null argument");
   if (w < 2 || h < 2) return fail(RT_ERR_BAD_ARG, "rt_primary_hits: image must be at least 2x2");
+  if ((uint64_t)w * h > 0xFFFFFFFFull / 3) return fail(RT_ERR_BAD_ARG, "rt_primary_hits: image too large");
   HIP_TRY(hipSetDevice(s->device));
   size_t n = (size_t)w * h;
   DeviceBuffers tmp;
@@ -1015,7 +1017,7 @@ int primary_to_host(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t h, u
   };
   uint32_t* d_id = nullptr;
   R *d_t = nullptr, *d_n = nullptr, *d_uv = nullptr;
-  uint8_t* d_ff = nullptr;
+  uint8_t *d_ff = nullptr, *d_unsure = nullptr;
   HIP_TRY(alloc(n * sizeof(uint32_t), (void**)&d_id));
   HIP_TRY(alloc(n * sizeof(R), (void**)&d_t));
   HIP_TRY(alloc(n * 3 * sizeof(R), (void**)&d_n));
@@ -1023,15 +1025,44 @@ int primary_to_host(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t h, u
   if (front_face) HIP_TRY(alloc(n, (void**)&d_ff));
   LaunchShape sh = make_shape(s, w, h, 1, fast && sizeof(R) == 4, cam, 0);
   sh.tiles = ((w + 15) / 16) * ((h + 15) / 16);  // the primary kernel is tile-per-workgroup whatever the render shape
-  if (fast && (time < s->safe_t_lo || time > s->safe_t_hi)) sh.trav = 0;
-  HIP_TRY(Side<R>::primary(Side<R>::get(s).view, to_camera<R>(*cam), w, h, seed, (R)time, d_id, d_t, d_n, d_uv, d_ff, sh,
-                           nullptr));
+  sh.ref_stack_depth = s->stack_depth;
+  if (fast && (time < s->safe_t_lo || time > s->safe_t_hi)) {
+    sh.trav = 0;
+    sh.stack_depth = s->stack_depth;
+  }
+  if constexpr (sizeof(R) == 4) {
+    // f32: the product walk, audited (device/audit.hpp); the pixels it marks are re-decided by the f64 audit kernel
+    HIP_TRY(alloc(n, (void**)&d_unsure));
+    const CameraView<double> cam64 = to_camera<double>(*cam);
+    HIP_TRY(launch_primary_audited_f32(s->f32.view, s->f64.view, cam64, w, h, seed, time, d_id, (float*)d_t, (float*)d_n,
+                                       (float*)d_uv, d_ff, d_unsure, sh, nullptr));
+    HIP_TRY(launch_primary_fix_f64(s->f64.view, cam64, w, h, seed, time, d_unsure, d_id, (float*)d_t, (float*)d_n, (float*)d_uv,
+                                   d_ff, s->stack_depth, nullptr));
+  } else {
+    HIP_TRY(Side<R>::primary(Side<R>::get(s).view, to_camera<R>(*cam), w, h, seed, (R)time, d_id, d_t, d_n, d_uv, d_ff, sh,
+                             nullptr));
+  }
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(prim_id, d_id, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(t, d_t, n * sizeof(R), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(normal, d_n, n * 3 * sizeof(R), hipMemcpyDeviceToHost));
   if (uv) HIP_TRY(hipMemcpy(uv, d_uv, n * 2 * sizeof(R), hipMemcpyDeviceToHost));
   if (front_face) HIP_TRY(hipMemcpy(front_face, d_ff, n, hipMemcpyDeviceToHost));
+  if (d_unsure) {
+    std::vector<uint8_t> flags(n);
+    HIP_TRY(hipMemcpy(flags.data(), d_unsure, n, hipMemcpyDeviceToHost));
+    uint64_t c = 0, why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint8_t f : flags) {
+      c += f != 0;
+      for (int b = 0; b < 8; ++b) why[b] += (f >> b) & 1;
+    }
+    s->last_redecided = c;
+    if (getenv("RT_AUDIT_REASONS"))  // diagnostic: which kind of decision sent pixels to the f64 kernel (device/audit.hpp AUD_*)
+      fprintf(stderr, "audit: %llu of %zu re-decided; node %llu cube %llu sphere-hit %llu sphere-window %llu medium %llu tie %llu accuracy %llu direction %llu\n",
+              (unsigned long long)c, n, (unsigned long long)why[0], (unsigned long long)why[1], (unsigned long long)why[2],
+              (unsigned long long)why[3], (unsigned long long)why[4], (unsigned long long)why[5], (unsigned long long)why[6],
+              (unsigned long long)why[7]);
+  }
   return RT_OK;
 }
 
@@ -1052,6 +1083,8 @@ int rt_primary_hits_fast(rt_scene* s, const rt_camera* cam, uint32_t w, uint32_t
                          uint32_t* prim_id, float* t, float* normal, float* uv, uint8_t* front_face) {
   return primary_to_host<float>(s, cam, w, h, seed, time, prim_id, t, normal, uv, front_face, true);
 }
+
+uint64_t rt_primary_redecided(const rt_scene* s) { return s ? s->last_redecided : 0; }
 
 int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* p, float* accum, rt_stats* stats) {
   return render_to_host<float>(s, cam, p, accum, stats);

@@ -4,4 +4,5 @@
 #define RT_REAL double
 #define RT_HAS_LINEAR 0
 #define RT_EARLY_EXIT false
+#define RT_DEFINE_F64_FIX 1
 #include "launch_impl.hpp"

@@ -46,25 +46,34 @@ def test_primary_hits_f64_exact(name, earthmap):
         np.testing.assert_allclose(guv[hit], ouv[hit], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("w", [64, 150])
 @pytest.mark.parametrize("name", list(SCENES))
-def test_primary_hits_f32(name, earthmap):
-    hs, ds, os_, h, _ = _pair(name, earthmap)
-    gid, gt, gn, guv, gff = ds.primary_hits(W, h, seed=3, time=0.25, f64=False)
-    oid, ot, on, ouv, off = os_.primary_hits(W, h, seed=3, time=0.25)
-    same = gid == oid
-    # f32 rounding may move a silhouette by a fraction of a pixel: allow <= 0.5 % of pixels
-    assert (~same).mean() <= 0.005, f"{name}: {(~same).sum()} of {same.size} primary ids differ"
-    hit = same & (oid != 0xFFFFFFFF)
-    rel_t = np.abs(gt[hit] - ot[hit]) / np.abs(ot[hit])
-    dn = np.abs(gn[hit] - on[hit]).max(axis=-1)
-    # north_star level 2: 1e-5 relative.  Report the worst case, require it on >= 99.5 % of pixels and
-    # 1e-3 everywhere (grazing hits on the r=1000 ground sphere lose digits to cancellation in f32).
-    print(f"{name}: f32 primary t rel err max {rel_t.max() if rel_t.size else 0:.3g} "
-          f"p99.5 {np.quantile(rel_t, 0.995) if rel_t.size else 0:.3g}; normal abs err max {dn.max() if dn.size else 0:.3g}")
-    if rel_t.size:
-        assert np.quantile(rel_t, 0.995) <= 1e-5
-        assert rel_t.max() <= 1e-3
-        assert np.quantile(dn, 0.995) <= 1e-4
+def test_primary_hits_f32(name, w, earthmap):
+    """north_star levels 1-2 for the f32 product walk (rt_primary_hits: the leaf arithmetic rt_render runs, audited by
+    device/audit.hpp; pixels whose decisions sit inside their f32 rounding bounds are re-decided in f64):
+    primitive ids and front_face EQUAL to the oracle's on every pixel, t within 1e-5 relative on every pixel.
+    The audit must stay a filter, not a detour: it may hand at most 8 % of the pixels to the f64 kernel.
+    Normals: 1e-5 is met wherever f32 STORAGE allows it — a sphere of radius r whose centre c is stored in f32 has
+    its normal (p - c) / r known to 2^-24 |c| / r at best (bvh_stress: r = 0.05 at |c| = 40 gives 5e-5) — so the
+    bound is 1e-5 on 95 % of the pixels and 3e-4 on all."""
+    hs, ds, os_, _, _ = _pair(name, earthmap)
+    h = max(2, int(w / SCENES[name][1]))
+    for fast in (False, True):
+        gid, gt, gn, guv, gff = ds.primary_hits(w, h, seed=3, time=0.25, f64=False, fast=fast)
+        redecided = ds.redecided
+        oid, ot, on, ouv, off = os_.primary_hits(w, h, seed=3, time=0.25)
+        assert np.array_equal(gid, oid), f"{name}: {(gid != oid).sum()} of {gid.size} primary ids differ"
+        hit = oid != 0xFFFFFFFF
+        assert np.array_equal(gff[hit], off[hit])
+        rel_t = np.abs(gt[hit] - ot[hit]) / np.abs(ot[hit])
+        dn = np.abs(gn[hit] - on[hit]).max(axis=-1)
+        print(f"{name} w={w} fast={fast}: re-decided {redecided}/{gid.size}; t rel err max {rel_t.max() if rel_t.size else 0:.3g}; "
+              f"normal abs err max {dn.max() if dn.size else 0:.3g}, p95 {np.quantile(dn, 0.95) if dn.size else 0:.3g}")
+        assert redecided <= 0.08 * gid.size, f"{name}: the audit sent {redecided} of {gid.size} pixels to f64"
+        if rel_t.size:
+            assert rel_t.max() <= 1e-5
+            assert np.quantile(dn, 0.95) <= 1e-5
+            assert dn.max() <= 3e-4
 
 
 @pytest.mark.parametrize("name", ["random_scene", "two_spheres", "earth", "simple_light", "cube_scene",

@@ -28,7 +28,7 @@ for name, (sid, asp, n, depth) in SCENES.items():
                 rel = np.abs(gt[hit] - ot[hit]) / np.abs(ot[hit])
                 dn = np.abs(gn[hit] - on[hit]).max(axis=-1)
                 duv = np.abs(guv[hit] - ouv[hit]).max(axis=-1) if hit.any() else np.zeros(1)
-                print(f"{name:20s} W={W:4d} fast={int(fast)} ids differ {diff.sum():5d}/{diff.size}  rel_t max {rel.max() if rel.size else 0:.3g} "
+                print(f"{name:20s} W={W:4d} fast={int(fast)} redecided {ds.redecided:5d} ids differ {diff.sum():5d}/{diff.size}  rel_t max {rel.max() if rel.size else 0:.3g} "
                       f"p99.9 {np.quantile(rel, 0.999) if rel.size else 0:.3g} n>1e-5: {(rel > 1e-5).sum()}  dn max {dn.max() if dn.size else 0:.3g} "
                       f"n>1e-5: {(dn > 1e-5).sum()}  duv max {duv.max():.3g} ff differ {(gff[hit] != off[hit]).sum()}", flush=True)
                 if diff.any() and not fast:
