@@ -310,6 +310,11 @@ RT_DEV bool leaf_t_unified(const SceneView<float>& sc, uint32_t ref, const RayT<
     const Real4<float> sp = sc.spheres[idx];
     p0 = Vec3<float>(sp.x, sp.y, sp.z);
     p1 = Vec3<float>(sp.w, 0.0f, 0.0f);
+    if constexpr (STATS) {  // a baked sphere (rt_api.hip) stands for its Rotate / Translate wrappers in the work counters
+      const uint32_t w = sc.sphere_attr[idx].pad;
+      cnt.template inc<ST_ROTATE>(w & 0xFFFFu);
+      cnt.template inc<ST_TRANSLATE>(w >> 16);
+    }
   } else {
     const MSphere<float> m = sc.mspheres[idx];
     p0 = moving_center(m, r.time);

@@ -616,24 +616,39 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
     __syncthreads();
   }
   const Light<R>* lights = sc.n_lights <= LDS_MAX_LIGHTS ? s_lights : sc.lights;
+  // A wave owns an 8x8 pixel tile and this block row's slice of the launch's samples: 64 x n_s (pixel, sample) JOBS.
+  // Jobs are not tied to lanes: whichever lane needs work takes the next job (j -> pixel j % 64, sample j / 64), so the
+  // lanes of a wave run out of work together, within one path of each other, whatever their paths' lengths (with a
+  // fixed quota per lane — its own pixel's samples — a wave lasts as long as its unluckiest lane, which costs most
+  // where quotas are small: BASELINE config C1, 400 x 225 at 100 spp, is 27 samples per lane of the chip).  A finished
+  // sample is added to its pixel's sum in LDS (ds_add_f32).  Paths and draws are unchanged: a sample's Philox stream is
+  // keyed by (pixel, sample), not by the lane that renders it; only the f32 order of a pixel's sample sum changes.
+  __shared__ float s_acc[BLOCK / 64][64 * 3];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t px, py;
   tile_pixel(a.width, px, py);
-  const uint32_t pixel = py * a.width + px;
+  const uint32_t tx0 = px - (lane & 7u), ty0 = py - (lane >> 3);  // the wave's tile origin
+  s_acc[wave][lane] = 0.0f;
+  s_acc[wave][64 + lane] = 0.0f;
+  s_acc[wave][128 + lane] = 0.0f;
+  __builtin_amdgcn_wave_barrier();
 
   Cnt<STATS> cnt;
   cnt.clear();
   uint32_t nonfinite = 0;
-  Vec3<R> acc;
   const Vec3<R> background(sc.background[0], sc.background[1], sc.background[2]);
-  uint32_t s = (uint32_t)(((uint64_t)a.n_samples * blockIdx.y) / a.splits);
+  const uint32_t s_begin = (uint32_t)(((uint64_t)a.n_samples * blockIdx.y) / a.splits);
   const uint32_t s_end = (uint32_t)(((uint64_t)a.n_samples * (blockIdx.y + 1)) / a.splits);
-  bool done = !(px < a.width && py < a.height) || s == s_end || a.max_depth == 0;  // main.rs:73-75: depth 0 -> black
+  const uint32_t total_jobs = 64u * (s_end - s_begin);  // wave-uniform
+  uint32_t next_job = 0;                                 // wave-uniform: jobs handed out so far
+  bool done = total_jobs == 0 || a.max_depth == 0;       // main.rs:73-75: depth 0 -> black
   bool alive = false, walking = false;
+  uint32_t lp = lane;  // the pixel of the job in flight (0..63 within the tile)
   RayT<R> ray;
   Vec3<R> thr, L;
   uint32_t depth_left = 0, slot = 0;
   Rng rng;
-  rng.init(a.seed, pixel, 0);
+  rng.init(a.seed, 0, 0);
   OrderedWalk walk;
   walk.cur = REF_NONE;
   walk.sp = 0;
@@ -647,23 +662,37 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
 #endif
   for (;;) {
     RT_STAMP(0);
-    // (1) lanes without a walk in progress: next camera sample if the path is over, then start the walk
-    if (!walking && !done) {
-      if (!alive) {
-        rng.sample = a.sample_begin + s;
-        ++s;
-        rng.begin(0);
-        R ju = rng.next<R>();
-        R jv = rng.next<R>();
-        R u = rdiv((R)px + ju, (R)(a.width - 1));                  // main.rs:161
-        R v = rdiv((R)(a.height - py - 1) + jv, (R)(a.height - 1));  // main.rs:162-163
-        ray = camera_ray(cam, u, v, rng);
-        thr = Vec3<R>(1, 1, 1);
-        L = Vec3<R>(0, 0, 0);
-        depth_left = a.max_depth;
-        slot = 1;
-        alive = true;
+    // (1) lanes without a walk in progress: next job if the path is over, then start the walk
+    {
+      const bool needy = !walking && !done && !alive;
+      const uint64_t m = __ballot(needy);
+      if (needy) {
+        const uint32_t j = next_job + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (j >= total_jobs) {
+          done = true;
+        } else {
+          lp = j & 63u;
+          const uint32_t jx = tx0 + (lp & 7u), jy = ty0 + (lp >> 3);
+          if (jx < a.width && jy < a.height) {  // (a tile that straddles the image edge: its outside jobs are dropped)
+            rng.pixel = jy * a.width + jx;
+            rng.sample = a.sample_begin + s_begin + (j >> 6);
+            rng.begin(0);
+            R ju = rng.next<R>();
+            R jv = rng.next<R>();
+            R u = rdiv((R)jx + ju, (R)(a.width - 1));                  // main.rs:161
+            R v = rdiv((R)(a.height - jy - 1) + jv, (R)(a.height - 1));  // main.rs:162-163
+            ray = camera_ray(cam, u, v, rng);
+            thr = Vec3<R>(1, 1, 1);
+            L = Vec3<R>(0, 0, 0);
+            depth_left = a.max_depth;
+            slot = 1;
+            alive = true;
+          }
+        }
       }
+      next_job += (uint32_t)__popcll(m);
+    }
+    if (!walking && alive) {
       rng.begin(slot);
       cnt.template inc<ST_RAYS>();
       walking = walk.start(sc, ray);
@@ -697,7 +726,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
     }
     RT_STAMP(5);
     // (3) lanes whose walk is over: one vertex of ray_color (main.rs:77-104)
-    if (!walking && !done) {
+    if (!walking && alive) {
       bool cont;
       if (walk.best == REF_NONE) {  // main.rs:104
         cnt.template inc<ST_MISSES>();
@@ -720,9 +749,12 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
       if (!cont) {
         const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
         if (!fin) ++nonfinite;
-        if (fin) acc = acc + L;
+        if (fin) {
+          atomicAdd(&s_acc[wave][3u * lp + 0u], L.x);
+          atomicAdd(&s_acc[wave][3u * lp + 1u], L.y);
+          atomicAdd(&s_acc[wave][3u * lp + 2u], L.z);
+        }
         alive = false;
-        if (s == s_end) done = true;
       }
     }
     RT_STAMP(6);
@@ -731,20 +763,22 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
   if ((threadIdx.x & 63) == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&stats->stamp[i], stamp_acc[i]);
 #endif
+  __builtin_amdgcn_wave_barrier();
   if (px < a.width && py < a.height) {
-    R* out = accum + 3ull * pixel;
+    R* out = accum + 3ull * (py * a.width + px);
+    const R ax = s_acc[wave][3u * lane + 0u], ay = s_acc[wave][3u * lane + 1u], az = s_acc[wave][3u * lane + 2u];
     if (a.splits > 1) {
-      atomicAdd(out + 0, acc.x);
-      atomicAdd(out + 1, acc.y);
-      atomicAdd(out + 2, acc.z);
+      atomicAdd(out + 0, ax);
+      atomicAdd(out + 1, ay);
+      atomicAdd(out + 2, az);
     } else if (a.accumulate) {
-      out[0] += acc.x;
-      out[1] += acc.y;
-      out[2] += acc.z;
+      out[0] += ax;
+      out[1] += ay;
+      out[2] += az;
     } else {
-      out[0] = acc.x;
-      out[1] = acc.y;
-      out[2] = acc.z;
+      out[0] = ax;
+      out[1] = ay;
+      out[2] = az;
     }
   }
   flush_stats(cnt, stats);

@@ -2,6 +2,7 @@
 // error reporting.  Host code only; the kernels live in device/*.hpp and are instantiated
 // by rt_f32.hip / rt_f64.hip.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -121,6 +122,54 @@ template <typename R> struct SceneSide {
 template <typename R>
 hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& complexes, const std::vector<uint32_t>& linear,
                       const TreeFacts& facts, SceneSide<R>& s) {
+  // BAKED spheres.  A Translate / Rotate chain (no medium) around a static Sphere whose material never reads uv is,
+  // for every quantity the path uses, a Sphere at the mapped centre: t is frame-independent, the world normal
+  // (p - c') / r is the rotated local normal, front_face follows.  Such complex leaves get a plain sphere record
+  // (centre mapped in f64 on the host) appended to the sphere arrays of BOTH precisions; the f32 trees reference that
+  // record instead of the complex (one 16-byte fetch and no rigid map per test: final_scene wraps each of its 1000
+  // small spheres this way, where the reference has one Translate(Rotate(Bvh)) instance), the f64 audit side keeps
+  // walking the literal wrapper chain (hittable.rs:364-386) and only holds the record for rt_primary_hits' audit.
+  std::vector<uint32_t> baked(d.n_complex, RT_REF_NONE);  // complex index -> index of its baked sphere record
+  std::vector<std::array<double, 4>> baked_sphere;
+  std::vector<Attr> baked_attr;
+  {
+    std::vector<uint8_t> tex_uv0(d.n_textures, 0);
+    for (uint32_t i = d.n_textures; i-- > 0;) {
+      if (d.tex_tag[i] == RT_TEX_IMAGE || d.tex_tag[i] == RT_TEX_UV) tex_uv0[i] = 1;
+      if (d.tex_tag[i] == RT_TEX_CHECKER) tex_uv0[i] = tex_uv0[d.tex_odd[i]] | tex_uv0[d.tex_even[i]];
+    }
+    static const bool no_bake = getenv("RT_NO_BAKE") != nullptr;  // A/B switch
+    for (uint32_t i = 0; i < d.n_complex && !no_bake; ++i) {
+      const Complex& cx = complexes[i];
+      if (cx.medium_pos != REF_NONE || RT_REF_KIND(cx.body) != RT_LEAF_SPHERE) continue;
+      const uint32_t bi = RT_REF_INDEX(cx.body), m = d.sphere_material[bi];
+      if (d.mat_texture[m] < d.n_textures && tex_uv0[d.mat_texture[m]]) continue;
+      // c_world: undo the wrappers innermost first (Rotate by q*, Translate by +offset), as leaf_world_bounds does
+      double p[3] = {d.sphere[4 * (size_t)bi], d.sphere[4 * (size_t)bi + 1], d.sphere[4 * (size_t)bi + 2]};
+      for (uint32_t k = cx.op_count; k-- > 0;) {
+        const uint32_t o = cx.op_first + k;
+        const double* q = d.op_data + 4 * (size_t)o;
+        if (d.op_tag[o] == RT_OP_TRANSLATE) {
+          for (int c = 0; c < 3; ++c) p[c] += q[c];
+        } else {
+          const double qi[4] = {q[0], -q[1], -q[2], -q[3]};
+          double r[3];
+          host_qrotate(p, qi, r);
+          for (int c = 0; c < 3; ++c) p[c] = r[c];
+        }
+      }
+      baked[i] = d.n_spheres + (uint32_t)baked_sphere.size();
+      baked_sphere.push_back({p[0], p[1], p[2], d.sphere[4 * (size_t)bi + 3]});
+      // pad: the wrapper visits one test of this leaf stands for (STATS builds keep the reference's work counters)
+      baked_attr.push_back(Attr{m, cx.object, facts.rank_complex[i], cx.n_rotate | (cx.n_translate << 16)});
+    }
+  }
+  auto f32_ref = [&](uint32_t ref) -> uint32_t {  // the leaf reference the f32 trees use
+    if (sizeof(R) == 4 && ref != RT_REF_NONE && (ref & RT_REF_LEAF) && RT_REF_KIND(ref) == RT_LEAF_COMPLEX &&
+        baked[RT_REF_INDEX(ref)] != RT_REF_NONE)
+      return RT_MAKE_LEAF(RT_LEAF_SPHERE, baked[RT_REF_INDEX(ref)]);
+    return ref;
+  };
   std::vector<Node<R>> nodes(d.n_nodes);
   for (uint32_t i = 0; i < d.n_nodes; ++i) {
     std::memset(&nodes[i], 0, sizeof(Node<R>));
@@ -128,8 +177,8 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
       nodes[i].lo[k] = conv_lo<R>(d.node_box[6 * (size_t)i + k]);
       nodes[i].hi[k] = conv_hi<R>(d.node_box[6 * (size_t)i + 3 + k]);
     }
-    nodes[i].left = d.node_left[i];
-    nodes[i].right = d.node_right[i];
+    nodes[i].left = f32_ref(d.node_left[i]);
+    nodes[i].right = f32_ref(d.node_right[i]);
   }
   // ordered-walk tree (f32): its own binned-SAH tree over the same leaves (accel_build.hpp); the
   // reference's tree above stays what the reference-order walk and parity level 1 use.  Each Node2
@@ -140,7 +189,9 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
     const bool own_tree = getenv("RT_ORDERED_REFERENCE_TREE") == nullptr;
     if (facts.conservative && facts.leaf_refs.size() >= 2 && own_tree) {
       const uint32_t n_leaves = (uint32_t)facts.leaf_refs.size();
-      nodes2 = accel::build_sah(facts.leaf_box.data(), facts.leaf_refs.data(), n_leaves,
+      std::vector<uint32_t> refs(facts.leaf_refs);
+      for (uint32_t& r : refs) r = f32_ref(r);
+      nodes2 = accel::build_sah(facts.leaf_box.data(), refs.data(), n_leaves,
                                 std::min(MAX_STACK_DEPTH, accel::ceil_log2(n_leaves) + 6u), &s.ordered_height);
       s.ordered_root = 0;
     } else if (facts.conservative && d.n_nodes > 0 && !(d.root & RT_REF_LEAF) && d.root != RT_REF_NONE) {
@@ -162,8 +213,8 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
         std::memset(&nodes2[i], 0, sizeof(Node2));
         child_box(d.node_left[i], nodes2[i].lbox);
         child_box(d.node_right[i], nodes2[i].rbox);
-        nodes2[i].left = d.node_left[i];
-        nodes2[i].right = d.node_right[i];
+        nodes2[i].left = f32_ref(d.node_left[i]);
+        nodes2[i].right = f32_ref(d.node_right[i]);
       }
       s.ordered_root = d.root;
       s.ordered_height = accel::height_of(nodes2, d.root);
@@ -175,6 +226,11 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
     const double* p = d.sphere + 4 * (size_t)i;
     spheres[i] = Real4<R>{conv<R>(p[0]), conv<R>(p[1]), conv<R>(p[2]), conv<R>(p[3])};
     sphere_attr[i] = Attr{d.sphere_material[i], d.sphere_object[i], facts.rank_sphere[i], 0};
+  }
+  for (size_t j = 0; j < baked_sphere.size(); ++j) {
+    const auto& p = baked_sphere[j];
+    spheres.push_back(Real4<R>{conv<R>(p[0]), conv<R>(p[1]), conv<R>(p[2]), conv<R>(p[3])});
+    sphere_attr.push_back(baked_attr[j]);
   }
   std::vector<MSphere<R>> mspheres(d.n_mspheres);
   std::vector<Attr> msphere_attr(d.n_mspheres);
@@ -327,7 +383,7 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
     linear_rec.assign(linear.size() * LIN_DWORDS, 0u);
     auto put = [&](size_t k, uint32_t off, float v) { std::memcpy(&linear_rec[k * LIN_DWORDS + off], &v, 4); };
     for (size_t k = 0; k < linear.size(); ++k) {
-      uint32_t ref = linear[k], body = ref, flags = 0, material = 0, object = 0;
+      uint32_t ref = f32_ref(linear[k]), body = ref, flags = 0, material = 0, object = 0;
       float nid = 0.0f;
       if (RT_REF_KIND(ref) == RT_LEAF_COMPLEX) {
         const uint32_t ci = RT_REF_INDEX(ref);
@@ -352,9 +408,13 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
         if (!(flags & LINF_MEDIUM)) material = d.cube_material[bi];
         if (RT_REF_KIND(ref) != RT_LEAF_COMPLEX) object = d.cube_object[bi];
       } else {
-        for (int c = 0; c < 4; ++c) put(k, LIN_PRIM + c, (float)d.sphere[4 * (size_t)bi + c]);
-        if (!(flags & LINF_MEDIUM)) material = d.sphere_material[bi];
-        if (RT_REF_KIND(ref) != RT_LEAF_COMPLEX) object = d.sphere_object[bi];
+        const Real4<R>& sp = spheres[bi];  // (incl. baked records)
+        put(k, LIN_PRIM + 0, (float)sp.x);
+        put(k, LIN_PRIM + 1, (float)sp.y);
+        put(k, LIN_PRIM + 2, (float)sp.z);
+        put(k, LIN_PRIM + 3, (float)sp.w);
+        if (!(flags & LINF_MEDIUM)) material = sphere_attr[bi].material;
+        if (RT_REF_KIND(ref) != RT_LEAF_COMPLEX) object = sphere_attr[bi].object;
       }
       linear_rec[k * LIN_DWORDS + LIN_FLAGS] = flags;
       linear_rec[k * LIN_DWORDS + LIN_REF] = ref;
@@ -380,7 +440,7 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
     if (f & LINF_CUBE) s.view.linear_cube_mask |= 1u << k;
     if (f & LINF_MEDIUM) s.view.linear_medium_mask |= 1u << k;
   }
-  s.view.root = d.root;
+  s.view.root = f32_ref(d.root);
   s.view.root2 = s.ordered_root;
   s.view.lights_kind = d.lights_kind;
   s.view.n_lights = d.n_lights;
@@ -818,8 +878,13 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   sh.leaf_shift = ls ? (uint32_t)std::min(5, std::max(0, atoi(ls))) : (n_nodes <= 4096 || n_nodes > 65536) ? 1u : 2u;
   uint32_t waves = sh.tiles * 4;
   static const char* tw = getenv("RT_TARGET_WAVES");  // tuning override
-  const uint32_t target = tw ? (uint32_t)std::max(1, atoi(tw)) : TARGET_WAVES;
+  // The refill kernel (ordered walk) hands a wave's jobs to whichever lane is free, so its waves end together whatever
+  // their size, and what is left to balance is the uneven cost of image regions ACROSS waves: many short waves
+  // (measured on final_scene 1024^2 x 512 spp: 24 k waves 6.4, 98 k 8.0, 197 k 8.3, 393 k 8.1, 1.5 M 6.3 Grays/s), but
+  // no fewer than 6 samples per wave and split (random_scene 400 x 225 x 100 spp: 16 splits 7.0, 64 splits 6.0 Grays/s)
+  const uint32_t target = tw ? (uint32_t)std::max(1, atoi(tw)) : (sh.trav == 2 ? 2u * TARGET_WAVES : TARGET_WAVES);
   uint32_t splits = waves >= target ? 1 : (target + waves - 1) / waves;
+  if (sh.trav == 2) splits = std::min(splits, std::max(1u, n_samples / 6u));
   sh.splits = std::max(1u, std::min(splits, n_samples));
   // Leaf-list scenes: persistent workers drawing (8x8 tile, sample range) units from a global counter
   // (render_persist_kernel).  Off for max_depth 0 (handled by render_kernel) and with RT_LINEAR_NO_PERSIST (A/B).

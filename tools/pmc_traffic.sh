@@ -2,7 +2,7 @@
 # L2<->fabric traffic of the default bench workload (full 4096-spp launch), two TCC passes.
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmct; rm -rf $out; mkdir -p $out
-B="$PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline $*"
+B="$PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f64-leg --no-other-configs $*"
 timeout -s KILL 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/a -o pmc -- python3 $B > $out/a.log 2>&1 || { tail -3 $out/a.log; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_ATOMIC_sum --output-format csv -d $out/b -o pmc -- python3 $B > $out/b.log 2>&1 || { tail -3 $out/b.log; exit 1; }
 python3 - $out <<'PY'
