@@ -171,6 +171,12 @@ typedef struct rt_camera {
                                  leaf-list fast path (same result; used to count the reference
                                  algorithm's node visits for the roofline's algorithmic work) */
 
+#define RT_FLAG_WAVEFRONT 4u  /* f32, BVH-bound scenes only (ignored elsewhere): render with the wavefront form — a pool of
+                                 paths in HBM, a TRACE and a SHADE kernel per bounce (device/wavefront.hpp) — instead of the
+                                 megakernel.  Same paths, same draws, same image up to f32 summation order.  Measured SLOWER
+                                 (DESIGN.md 3.3): kept as the evidence for the megakernel-versus-queue question.  The call
+                                 allocates the pool on first use (72 B per slot, 2^21 slots) and synchronises the stream. */
+
 typedef struct rt_params {
   uint32_t width, height;   /* image size; h = trunc(w / aspect) is the caller's job (main.rs:112) */
   uint32_t spp;             /* samples per pixel rendered by THIS call */

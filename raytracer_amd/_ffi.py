@@ -17,6 +17,7 @@ RT_REF_NONE = 0xFFFFFFFF
 RT_LEAF_SPHERE, RT_LEAF_MSPHERE, RT_LEAF_CUBE, RT_LEAF_COMPLEX = 0, 1, 2, 3
 RT_FLAG_STATS = 1
 RT_FLAG_FORCE_BVH = 2
+RT_FLAG_WAVEFRONT = 4
 RT_OK, RT_ERR_BAD_ARG, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_STACK_DEPTH = 0, 1, 2, 3, 4
 
 _p = C.c_void_p

@@ -169,18 +169,20 @@ class DeviceScene:
         self.redecided = int(F.hip.rt_primary_redecided(self._h))  # f32: pixels the audit handed to the f64 kernel
         return ids, t, nrm, uv, ff
 
-    def _params(self, width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh=False):
+    def _params(self, width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh=False,
+                wavefront=False):
         p = F.RtParams()
         p.width, p.height, p.spp, p.max_depth = width, height, spp, max_depth
         p.seed, p.sample_offset = seed, sample_offset
         p.spp_per_launch = spp_per_launch
-        p.flags = (F.RT_FLAG_STATS if stats else 0) | (F.RT_FLAG_FORCE_BVH if force_bvh else 0)
+        p.flags = ((F.RT_FLAG_STATS if stats else 0) | (F.RT_FLAG_FORCE_BVH if force_bvh else 0)
+                   | (F.RT_FLAG_WAVEFRONT if wavefront else 0))
         return p
 
     def render(self, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0, stats=False,
-               f64=False, camera=None, force_bvh=False):
+               f64=False, camera=None, force_bvh=False, wavefront=False):
         """The render closure main.rs:154-167 for every pixel: returns (accum SUM [h][w][3], stats dict)."""
-        p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh)
+        p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh, wavefront)
         accum = np.zeros((height, width, 3), dtype=np.float64 if f64 else np.float32)
         st = F.RtStats()
         fn = F.hip.rt_render_f64 if f64 else F.hip.rt_render
@@ -190,10 +192,10 @@ class DeviceScene:
 
     def render_device(self, accum_ptr, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0,
                       accumulate=False, stream=None, want_stats=True, stats=False, camera=None, force_bvh=False,
-                      f64=False, noalloc=False):
+                      f64=False, noalloc=False, wavefront=False):
         """Same, into DEVICE memory (accum_ptr = raw device address of a float32 [h][w][3] buffer; float64 with
         f64=True: rt_render_f64_device).  noalloc=True: rt_render_device_noalloc (static scratch, no allocation)."""
-        p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh)
+        p = self._params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats, force_bvh, wavefront)
         st = F.RtStats()
         cam = camera if camera is not None else self.host.camera
         fn = F.hip.rt_render_f64_device if f64 else (F.hip.rt_render_device_noalloc if noalloc else F.hip.rt_render_device)

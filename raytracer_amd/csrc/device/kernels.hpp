@@ -1501,3 +1501,7 @@ __global__ void kat_philox_kernel(uint32_t n, const uint32_t* ctr, const uint32_
 #endif  // RT_DEFINE_COMMON
 
 }  // namespace rt
+
+#if RT_HAS_LINEAR
+#include "wavefront.hpp"  // f32 only: the queue form of the ordered-walk path
+#endif

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device/scene_view.hpp"
+#include "device/wf_types.hpp"
 
 namespace rt {
 
@@ -47,6 +48,12 @@ hipError_t launch_primary_audited_f32(const SceneView<float>& sc, const SceneVie
 hipError_t launch_primary_fix_f64(const SceneView<double>& sc, const CameraView<double>& cam, uint32_t width, uint32_t height,
                                   uint64_t seed, double time, const uint8_t* unsure, uint32_t* prim_id, float* t, float* normal,
                                   float* uv, uint8_t* front_face, uint32_t ref_stack_depth, hipStream_t st);
+// wavefront path (device/wavefront.hpp, rt_f32.hip)
+hipError_t launch_wf_init(const CameraView<float>& cam, const WfArgs& a, const WfPool& pool, WfCounters* ctr, hipStream_t st);
+hipError_t launch_wf_iteration(const SceneView<float>& sc, const CameraView<float>& cam, const WfArgs& a, const WfPool& pool,
+                               WfCounters* ctr, uint32_t parity, float* accum, DeviceStats* dstats, bool stats,
+                               uint32_t trace_blocks, hipStream_t st);
+hipError_t wf_trace_blocks_per_cu(size_t lds_bytes, int* out);
 hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t* out, hipStream_t st);
 hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, hipStream_t st);
 hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, int path_stream, uint32_t* out,

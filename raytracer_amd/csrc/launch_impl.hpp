@@ -147,6 +147,30 @@ hipError_t launch_primary_audited_f32(const SceneView<float>& sc, const SceneVie
   return hipGetLastError();
 }
 #endif
+#if RT_HAS_LINEAR
+hipError_t launch_wf_init(const CameraView<float>& cam, const WfArgs& a, const WfPool& pool, WfCounters* ctr, hipStream_t st) {
+  hipLaunchKernelGGL(wf_init_kernel, dim3((pool.n_slots + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, cam, a, pool, ctr);
+  return hipGetLastError();
+}
+hipError_t launch_wf_iteration(const SceneView<float>& sc, const CameraView<float>& cam, const WfArgs& a, const WfPool& pool,
+                               WfCounters* ctr, uint32_t parity, float* accum, DeviceStats* dstats, bool stats,
+                               uint32_t trace_blocks, hipStream_t st) {
+  const size_t lds = (size_t)a.stack_depth * BLOCK * sizeof(uint32_t);
+  const size_t lds2 = lds + lds / 2;  // 32-bit refs + 16-bit entry distances
+  const dim3 shade_grid((pool.n_slots + BLOCK - 1) / BLOCK);
+  if (stats) {
+    hipLaunchKernelGGL((wf_trace_kernel<true>), dim3(trace_blocks), dim3(BLOCK), lds2, st, sc, a, pool, ctr, parity, dstats);
+    hipLaunchKernelGGL((wf_shade_kernel<true>), shade_grid, dim3(BLOCK), 0, st, sc, cam, a, pool, ctr, parity, accum, dstats);
+  } else {
+    hipLaunchKernelGGL((wf_trace_kernel<false>), dim3(trace_blocks), dim3(BLOCK), lds2, st, sc, a, pool, ctr, parity, dstats);
+    hipLaunchKernelGGL((wf_shade_kernel<false>), shade_grid, dim3(BLOCK), 0, st, sc, cam, a, pool, ctr, parity, accum, dstats);
+  }
+  return hipGetLastError();
+}
+hipError_t wf_trace_blocks_per_cu(size_t lds_bytes, int* out) {
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, wf_trace_kernel<false>, BLOCK, lds_bytes);
+}
+#endif
 #ifdef RT_DEFINE_F64_FIX
 hipError_t launch_primary_fix_f64(const SceneView<double>& sc, const CameraView<double>& cam, uint32_t width, uint32_t height,
                                   uint64_t seed, double time, const uint8_t* unsure, uint32_t* prim_id, float* t, float* normal,

@@ -595,10 +595,19 @@ struct rt_scene {
   SceneSide<float> f32;
   SceneSide<double> f64;
   uint64_t last_redecided = 0;  // rt_primary_redecided
+  // wavefront path (device/wavefront.hpp): the path pool, allocated at the first render that takes it
+  void* wf_mem = nullptr;
+  uint32_t wf_capacity = 0;       // slots
+  WfCounters* wf_ctr = nullptr;   // device
+  unsigned int* wf_host = nullptr;  // pinned: the `retired` count as last read
+  uint32_t wf_trace_blocks = 0;
   DeviceStats* dstats = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   ~rt_scene() {
     if (dstats) (void)hipFree(dstats);
+    if (wf_mem) (void)hipFree(wf_mem);
+    if (wf_ctr) (void)hipFree(wf_ctr);
+    if (wf_host) (void)hipHostFree(wf_host);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
   }
@@ -968,6 +977,103 @@ int check_params(const rt_params* p, const char* who) {
   return RT_OK;
 }
 
+// The wavefront form of one render call (device/wavefront.hpp): BVH-bound scenes, f32.  Synchronises the stream every few
+// iterations to read how many pool slots have retired (the host decides when the pool has drained).
+int render_wavefront(rt_scene* s, const rt_camera* cam, const rt_params* p, float* d_accum, int accumulate, hipStream_t stream,
+                     rt_stats* stats, const LaunchShape& shape) {
+  const bool want_stats = (p->flags & RT_FLAG_STATS) != 0;
+  static const char* slots_env = getenv("RT_WF_SLOTS");
+  const uint32_t max_slots = slots_env ? (uint32_t)std::max(256, atoi(slots_env)) : (1u << 21);
+  WfArgs a{};
+  a.width = p->width;
+  a.height = p->height;
+  a.sample_begin = (uint32_t)p->sample_offset;
+  a.n_samples = p->spp;
+  a.max_depth = p->max_depth;
+  a.tiles_x = (p->width + 7) / 8;
+  a.n_tiles = a.tiles_x * ((p->height + 7) / 8);
+  a.total_jobs = 64ull * a.n_tiles * p->spp;
+  a.stack_depth = shape.stack_depth;
+  static const char* re = getenv("RT_WF_REFILL_EIGHTHS");
+  a.refill_eighths = re ? (uint32_t)std::min(8, std::max(1, atoi(re))) : 2u;
+  a.leaf_shift = shape.leaf_shift;
+  a.has_media = 1u;  // (cheap: 20 bytes more per fetched ray; every scene may hold a medium)
+  a.seed = p->seed;
+  const uint32_t n_slots = (uint32_t)std::min<uint64_t>(max_slots, (a.total_jobs + 255) / 256 * 256);
+  a.n_blocks = (uint64_t)a.n_tiles * p->spp;
+  if (s->wf_capacity < n_slots) {
+    if (s->wf_mem) (void)hipFree(s->wf_mem);
+    s->wf_mem = nullptr;
+    s->wf_capacity = 0;
+    const size_t per_slot = 4 * sizeof(float4) + 5 * sizeof(uint32_t);  // ray_o, ray_d, thr_l, l_ids; hit, slot, list[2], group_next (1/64 used)
+    HIP_TRY(hipMalloc(&s->wf_mem, std::max<size_t>((size_t)n_slots * per_slot, 256)));
+    s->wf_capacity = n_slots;
+  }
+  if (!s->wf_ctr) HIP_TRY(hipMalloc((void**)&s->wf_ctr, sizeof(WfCounters)));
+  if (!s->wf_host) HIP_TRY(hipHostMalloc((void**)&s->wf_host, 64));
+  const size_t lds = (size_t)a.stack_depth * 256 * 6;
+  if (!s->wf_trace_blocks) {
+    int per_cu = 0, cus = 0;
+    HIP_TRY(wf_trace_blocks_per_cu(lds, &per_cu));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
+    s->wf_trace_blocks = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, cus);
+  }
+  WfPool pool{};
+  {
+    unsigned char* base = (unsigned char*)s->wf_mem;
+    const size_t cap = s->wf_capacity;
+    pool.ray_o = (float4*)base;
+    pool.ray_d = pool.ray_o + cap;
+    pool.thr_l = pool.ray_d + cap;
+    pool.l_ids = pool.thr_l + cap;
+    pool.hit = (uint32_t*)(pool.l_ids + cap);
+    pool.slot = pool.hit + cap;
+    pool.list[0] = pool.slot + cap;
+    pool.list[1] = pool.list[0] + cap;
+    pool.n_slots = n_slots;
+  }
+  const CameraView<float> cv = to_camera<float>(*cam);
+  const size_t accum_bytes = (size_t)p->width * p->height * 3 * sizeof(float);
+  HIP_TRY(hipMemsetAsync(s->dstats, 0, sizeof(DeviceStats), stream));
+  HIP_TRY(hipMemsetAsync(s->wf_ctr, 0, sizeof(WfCounters), stream));
+  if (!accumulate) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
+  HIP_TRY(hipEventRecord(s->ev0, stream));
+  HIP_TRY(launch_wf_init(cv, a, pool, s->wf_ctr, stream));
+  uint32_t iter = 0;
+  const uint32_t trace_blocks = (n_slots + 4 * WF_TRACE_ENTRIES - 1) / (4 * WF_TRACE_ENTRIES);
+  static const char* ce = getenv("RT_WF_CHECK_EVERY");
+  const uint32_t check_every = ce ? (uint32_t)std::max(1, atoi(ce)) : 8u;
+  // TAIL mode: once slots retire (their group's jobs are spent), the shade kernel writes the list of the slots still
+  // alive and the kernels walk that list instead of all slots
+  bool tail = false;
+  for (;;) {
+    for (uint32_t k = 0; k < check_every; ++k, ++iter) {
+      a.in_list = a.out_list;  // (a list exists once an iteration has written it)
+      a.out_list = tail ? 1u : 0u;
+      HIP_TRY(launch_wf_iteration(s->f32.view, cv, a, pool, s->wf_ctr, iter & 1u, d_accum, s->dstats, want_stats, trace_blocks,
+                                  stream));
+    }
+    HIP_TRY(hipMemcpyAsync(s->wf_host, &s->wf_ctr->retired, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (*s->wf_host >= n_slots) break;
+    if (*s->wf_host > 0) tail = true;
+    if (iter > (1u << 26)) return fail(RT_ERR_HIP, "rt_render: the wavefront pool did not drain");
+  }
+  HIP_TRY(hipEventRecord(s->ev1, stream));
+  if (stats) {
+    DeviceStats hs;
+    HIP_TRY(hipMemcpyAsync(&hs, s->dstats, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::memset(stats, 0, sizeof(*stats));
+    stats_to_abi(hs, stats);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->kernel_ms = ms;
+    stats->launches = 1 + 2 * iter;
+  }
+  return RT_OK;
+}
+
 // Enqueue the launches of one render call on `stream`; accum is device memory.
 // blocks / n_blocks: the DeviceStats scratch.  n_blocks == 1 (the scene's own block, allocated by rt_scene_create):
 // every launch uses it, its unit counter is re-zeroed between launches.  n_blocks > 1 (rt_render_device_noalloc: the
@@ -994,6 +1100,16 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
   auto block = [&](uint32_t i) { return reinterpret_cast<DeviceStats*>(blocks + (slots ? (size_t)i * NOALLOC_SLOT_BYTES : 0)); };
   HIP_TRY(hipSetDevice(s->device));
   const bool want_stats = (p->flags & RT_FLAG_STATS) != 0;
+  if constexpr (sizeof(R) == 4) {
+    // BVH-bound scenes: the wavefront form, opt-in (RT_FLAG_WAVEFRONT, or RT_WAVEFRONT=1 in the environment); never for
+    // the entry that must not allocate
+    static const bool wavefront_env = getenv("RT_WAVEFRONT") != nullptr;
+    const bool wavefront = wavefront_env || (p->flags & RT_FLAG_WAVEFRONT) != 0;
+    if (wavefront && !slots && p->spp > 0 && !(p->flags & RT_FLAG_FORCE_BVH)) {
+      const LaunchShape sh0 = make_shape(s, p->width, p->height, p->spp, true, cam, p->max_depth);
+      if (sh0.trav == 2) return render_wavefront(s, cam, p, (float*)d_accum, accumulate, stream, stats, sh0);
+    }
+  }
   CameraView<R> cv = to_camera<R>(*cam);
   const SceneView<R>& sv = Side<R>::get(s).view;
   HIP_TRY(hipMemsetAsync(blocks, 0, slots ? std::max<size_t>(n_launches, 1) * NOALLOC_SLOT_BYTES : sizeof(DeviceStats), stream));
