@@ -249,7 +249,8 @@ def other_configs(R, torch, device):
                       "ms_per_step": 1e3 * secs / steps, "value": rays / secs / 1e6, "unit": "Mrays/s",
                       "msamples_per_s": samples / secs / 1e6, "rays_per_sample": rays / samples,
                       "nonfinite_samples_dropped": nonfinite, "dtype": "f32",
-                      "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+                      "roofline": {k: rl[k] for k in rl if k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "note",
+                                                      "traffic_source",
                                                       "avg_launch_ms", "algorithmic_flops_per_ray",
                                                       "algorithmic_bytes_per_ray", "frac_valu_fp32", "frac_hbm",
                                                       "scene_bytes")}})

@@ -280,12 +280,29 @@ int rt_render_device_noalloc(rt_scene* scene, const rt_camera* cam, const rt_par
                              float* accum_rgb_device, int accumulate, void* stream, rt_stats* stats);
 
 /* Replaces: the same closure (main.rs:154-167) with rayon's worker pool (main.rs:157) lifted from
- * cores to the GPUs of one node, in ONE process: one host thread per entry of `devices` builds its
- * own device copy of the scene and renders samples [g*spp/G, (g+1)*spp/G) of every pixel (the
- * union of the Philox streams does not depend on G); the shards are summed on devices[0] over
- * xGMI peer copies and written to the HOST buffer accum_rgb ([h][w][3] f32 SUM).  A device may be
- * listed more than once.  per_dev: null or G entries (per-shard counters and kernel time).
- * One process per GPU + RCCL all-reduce (raytracer_amd/distributed.py) is the other way to do it. */
+ * cores to the GPUs of one node, in ONE process.  An rt_multi keeps, per entry of `devices` (a device
+ * may be listed more than once), a device copy of the scene, an accumulator and a stream, so that a
+ * sequence of renders (progressive passes, camera moves) pays for the G uploads once — the way the
+ * reference's workers share one `world` for the whole run (main.rs:138, 157).
+ * rt_multi_render: entry g renders samples rt_multi_shard(spp, g, G) of every pixel on its own stream
+ * (the union of the shards' Philox streams does not depend on G); each shard but the first is then
+ * peer-copied, on that same stream, into its own slot of a staging area on devices[0] — the G-1 copies
+ * run concurrently, one per xGMI link — and one kernel on devices[0] adds the slots to the first shard in
+ * shard order once all have landed.  The sum is written to the HOST buffer accum_rgb ([h][w][3] f32 SUM);
+ * the call returns when it is there.  per_dev: null, or G entries (per-shard counters and kernel time;
+ * each shard's thread then waits for its own counters before it starts its copy).
+ * One rt_multi serves one rt_multi_render at a time.
+ * One process per GPU + RCCL all-reduce (raytracer_amd/distributed.py) is the other way to do it.   */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(int n_dev, const int* devices, const rt_scene_desc* desc, rt_multi** out);
+int rt_multi_render(rt_multi* multi, const rt_camera* cam, const rt_params* params, float* accum_rgb,
+                    rt_stats* per_dev);
+void rt_multi_destroy(rt_multi* multi);
+/* The sample range of shard g of n_dev: first = g*spp/n_dev, count = (g+1)*spp/n_dev - first (integer
+ * division): contiguous, disjoint, covering [0, spp) for any n_dev, sizes within one of each other.
+ * Host arithmetic only (no GPU call): the distributed path's ranks use the same rule.              */
+void rt_multi_shard(uint64_t spp, uint32_t g, uint32_t n_dev, uint64_t* first, uint64_t* count);
+/* rt_multi_create + one rt_multi_render + rt_multi_destroy.                                         */
 int rt_render_multi(int n_dev, const int* devices, const rt_scene_desc* desc, const rt_camera* cam,
                     const rt_params* params, float* accum_rgb, rt_stats* per_dev);
 

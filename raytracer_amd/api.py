@@ -204,14 +204,59 @@ class DeviceScene:
         return st.as_dict() if want_stats else None
 
 
-def render_multi(host_scene, devices, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0,
-                 stats=False, camera=None):
-    """rt_render_multi: one host thread per device, samples sharded, shards summed on devices[0].
-    Returns (accum SUM [h][w][3] float32, [per-device stats dict])."""
+def _multi_params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats):
     p = F.RtParams()
     p.width, p.height, p.spp, p.max_depth = width, height, spp, max_depth
     p.seed, p.sample_offset, p.spp_per_launch = seed, sample_offset, spp_per_launch
     p.flags = F.RT_FLAG_STATS if stats else 0
+    return p
+
+
+class MultiScene:
+    """An rt_multi: the scene resident on every listed GPU of this process, kept across renders."""
+
+    def __init__(self, host_scene, devices):
+        self.host = host_scene
+        self.devices = list(devices)
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        F.check_hip(F.hip.rt_multi_create(len(self.devices), devs, C.byref(host_scene.desc), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            F.hip.rt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0, stats=False,
+               per_device=True, camera=None):
+        """rt_multi_render.  Returns (accum SUM [h][w][3] float32, [per-device stats dict] or None)."""
+        p = _multi_params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats)
+        st = (F.RtStats * len(self.devices))() if per_device else None
+        accum = np.zeros((height, width, 3), dtype=np.float32)
+        cam = camera if camera is not None else self.host.camera
+        F.check_hip(F.hip.rt_multi_render(self._h, C.byref(cam), C.byref(p), _ptr(accum), st))
+        return accum, ([s.as_dict() for s in st] if per_device else None)
+
+
+def multi_shard(spp, g, n_dev):
+    """rt_multi_shard: (first, count) of shard g of n_dev — host arithmetic, no GPU."""
+    first, count = C.c_uint64(), C.c_uint64()
+    F.hip.rt_multi_shard(spp, g, n_dev, C.byref(first), C.byref(count))
+    return int(first.value), int(count.value)
+
+
+def render_multi(host_scene, devices, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0,
+                 stats=False, camera=None):
+    """rt_render_multi: one host thread per device, samples sharded, shards summed on devices[0].
+    Returns (accum SUM [h][w][3] float32, [per-device stats dict])."""
+    p = _multi_params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats)
     devs = (C.c_int * len(devices))(*devices)
     st = (F.RtStats * len(devices))()
     accum = np.zeros((height, width, 3), dtype=np.float32)

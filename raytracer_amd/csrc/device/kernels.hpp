@@ -393,9 +393,46 @@ template <bool STATS> RT_DEV void flush_stats(const Cnt<STATS>& cnt, DeviceStats
   }
 }
 
-RT_DEV void tile_pixel(uint32_t width, uint32_t& px, uint32_t& py) {
+// Which (tile, sample split) a workgroup renders.  Workgroups go to the 8 XCDs round-robin by linear id, and each
+// XCD has its own L2.  mode 0: tile = blockIdx.x, split = blockIdx.y — the workgroups resident on one XCD at a time are
+// every 8th tile of a stretch 8x as long as it need be.  mode 1 (gridDim.y a multiple of 8): XCD x renders the splits
+// x, x + 8, ... of EVERY tile, tiles in order — the workgroups it runs side by side are neighbours in the image (they
+// walk the same part of the tree and find it in their L2), and all 8 XCDs have the same work whatever the image
+// looks like (each renders the whole image, 1/8 of the samples).  mode >= 2: slots dealt in chunks of `mode` (kept for
+// experiments).  All are bijections on the grid's slots: which pixels and samples are rendered does not change.
+RT_DEV void block_slot(uint32_t mode, uint32_t& tile, uint32_t& split) {
+  tile = blockIdx.x;
+  split = blockIdx.y;
+  if (mode == 0) return;
+  const uint32_t total = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+  const uint32_t x = id & 7u, i = id >> 3;  // XCD x runs ids x, x + 8, ...: this is its i-th workgroup
+  if (mode == 1) {
+    if (gridDim.y & 7u) return;
+    const uint32_t k = i / gridDim.x;
+    split = x + 8u * k;
+    tile = i - k * gridDim.x;
+    return;
+  }
+  const uint32_t round = mode * 8u;
+  if (id >= total - total % round) return;
+  const uint32_t f = ((i / mode) * 8u + x) * mode + i % mode;
+  split = f / gridDim.x;
+  tile = f - split * gridDim.x;
+}
+
+// Tile order within the image: bands of `band` tile rows, walked column by column, so that a run of consecutive
+// tiles (what one XCD has resident at a time) is a compact block of the image rather than a few long rows.
+// band <= 1: plain row-major.  A bijection on [0, tiles_x * tiles_y).
+RT_DEV uint32_t band_order(uint32_t i, uint32_t tiles_x, uint32_t tiles_y, uint32_t band) {
+  if (band <= 1u) return i;
+  const uint32_t per_band = band * tiles_x, b = i / per_band, within = i - b * per_band;
+  const uint32_t rows = min(band, tiles_y - b * band);  // the last band may be lower
+  const uint32_t col = within / rows, row = b * band + (within - col * rows);
+  return row * tiles_x + col;
+}
+
+RT_DEV void tile_pixel(uint32_t width, uint32_t& px, uint32_t& py, uint32_t tile = blockIdx.x) {
   const uint32_t tiles_x = (width + 15u) / 16u;
-  const uint32_t tile = blockIdx.x;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   px = (tile % tiles_x) * 16u + (wave & 1u) * 8u + (lane & 7u);
   py = (tile / tiles_x) * 16u + (wave >> 1) * 8u + (lane >> 3);
@@ -431,6 +468,8 @@ struct RenderArgs {
   uint32_t unit_samples;    // render_persist_kernel: samples per (8x8 tile, sample range) unit
   uint32_t wave_tiles_x, wave_tiles, total_units;
   uint32_t leaf_shift;  // refill kernel: run the leaf tests once (walking lanes >> leaf_shift) lanes wait at a leaf
+  uint32_t xcd_chunk;   // refill kernel: block_slot's mode
+  uint32_t tile_band;   // refill kernel: band_order's band height in tiles
   uint64_t seed;
 };
 
@@ -625,8 +664,10 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
   // keyed by (pixel, sample), not by the lane that renders it; only the f32 order of a pixel's sample sum changes.
   __shared__ float s_acc[BLOCK / 64][64 * 3];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t px, py;
-  tile_pixel(a.width, px, py);
+  uint32_t px, py, my_tile, my_split;
+  block_slot(a.xcd_chunk, my_tile, my_split);
+  my_tile = band_order(my_tile, (a.width + 15u) / 16u, (a.height + 15u) / 16u, a.tile_band);
+  tile_pixel(a.width, px, py, my_tile);
   const uint32_t tx0 = px - (lane & 7u), ty0 = py - (lane >> 3);  // the wave's tile origin
   s_acc[wave][lane] = 0.0f;
   s_acc[wave][64 + lane] = 0.0f;
@@ -637,8 +678,8 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
   cnt.clear();
   uint32_t nonfinite = 0;
   const Vec3<R> background(sc.background[0], sc.background[1], sc.background[2]);
-  const uint32_t s_begin = (uint32_t)(((uint64_t)a.n_samples * blockIdx.y) / a.splits);
-  const uint32_t s_end = (uint32_t)(((uint64_t)a.n_samples * (blockIdx.y + 1)) / a.splits);
+  const uint32_t s_begin = (uint32_t)(((uint64_t)a.n_samples * my_split) / a.splits);
+  const uint32_t s_end = (uint32_t)(((uint64_t)a.n_samples * (my_split + 1)) / a.splits);
   const uint32_t total_jobs = 64u * (s_end - s_begin);  // wave-uniform
   uint32_t next_job = 0;                                 // wave-uniform: jobs handed out so far
   bool done = total_jobs == 0 || a.max_depth == 0;       // main.rs:73-75: depth 0 -> black
@@ -1456,11 +1497,16 @@ __global__ void tonemap_kernel(const float* __restrict__ accum, uint64_t n, floa
   }
 }
 
-// dst += src over n floats (n a multiple of 1 float; the accumulators of two devices' sample shards)
-__global__ void accum_add_kernel(float* __restrict__ dst, const float* __restrict__ src, uint64_t n) {
+// dst[i] = ((dst[i] + src[i]) + src[n + i]) + ... over n_src images of n floats each, in that order (the accumulators
+// of the other devices' sample shards, rt_multi_render)
+__global__ void accum_add_kernel(float* __restrict__ dst, const float* __restrict__ src, uint64_t n, uint32_t n_src) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) dst[i] += src[i];
+  for (; i < n; i += stride) {
+    float a = dst[i];
+    for (uint32_t k = 0; k < n_src; ++k) a += src[(uint64_t)k * n + i];
+    dst[i] = a;
+  }
 }
 
 #endif  // RT_DEFINE_COMMON

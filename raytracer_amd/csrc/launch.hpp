@@ -18,6 +18,8 @@ struct LaunchShape {
   uint32_t ref_stack_depth = 1;  // ... of the reference's tree (the audit walk of rt_primary_hits always walks that one)
   uint32_t refill_eighths = 2;  // ordered walk: see RenderArgs::refill_eighths
   uint32_t leaf_shift = 2;      // ordered walk: see RenderArgs::leaf_shift
+  uint32_t xcd_chunk = 0;       // refill kernel: see RenderArgs::xcd_chunk
+  uint32_t tile_band = 1;       // refill kernel: see RenderArgs::tile_band
   // leaf-list scenes, persistent kernel (render_persist_kernel): 0 = off
   uint32_t unit_samples = 0, wave_tiles_x = 0, wave_tiles = 0, total_units = 0;
   int trav;              // 0 reference-order BVH walk, 1 leaf list, 2 ordered BVH walk (f32 only for 1, 2)
@@ -55,7 +57,7 @@ hipError_t launch_wf_iteration(const SceneView<float>& sc, const CameraView<floa
                                uint32_t trace_blocks, hipStream_t st);
 hipError_t wf_trace_blocks_per_cu(size_t lds_bytes, int* out);
 hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t* out, hipStream_t st);
-hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, hipStream_t st);
+hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, uint32_t n_src, hipStream_t st);
 hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, int path_stream, uint32_t* out,
                              hipStream_t st);
 

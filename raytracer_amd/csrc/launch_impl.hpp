@@ -7,6 +7,16 @@
 
 namespace rt {
 
+// A launcher reports its own launch's error: hipGetLastError() is sticky per host thread, so an error some EARLIER call
+// left behind (the caller's own HIP calls included — e.g. a refused hipSetDevice) is read and dropped first.
+#ifndef RT_LAUNCH
+#define RT_LAUNCH(...)               \
+  do {                               \
+    (void)hipGetLastError();         \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+#endif
+
 #define RT_CAT_(a, b) a##b
 #define RT_CAT(a, b) RT_CAT_(a, b)
 
@@ -33,12 +43,14 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   a.wave_tiles = shape.wave_tiles;
   a.total_units = shape.total_units;
   a.leaf_shift = shape.leaf_shift;
+  a.xcd_chunk = shape.xcd_chunk;
+  a.tile_band = shape.tile_band;
 #if RT_HAS_LINEAR
   if (shape.trav == TRAV_LINEAR && shape.unit_samples > 0) {  // persistent form: grid = workers, not tiles
     if (stats)
-      hipLaunchKernelGGL((render_persist_kernel<true>), grid, block, 0, st, sc, cam, a, accum, dstats);
+      RT_LAUNCH((render_persist_kernel<true>), grid, block, 0, st, sc, cam, a, accum, dstats);
     else
-      hipLaunchKernelGGL((render_persist_kernel<false>), grid, block, 0, st, sc, cam, a, accum, dstats);
+      RT_LAUNCH((render_persist_kernel<false>), grid, block, 0, st, sc, cam, a, accum, dstats);
     return hipGetLastError();
   }
   if (shape.trav == TRAV_LINEAR) {
@@ -46,16 +58,16 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
     static const bool sorted = getenv("RT_LINEAR_SORTED") != nullptr;
     if (sorted && max_depth > 0 && max_depth < 65536) {
       if (stats)
-        hipLaunchKernelGGL((render_sorted_kernel<true>), grid, block, 0, st, sc, cam, a, accum, dstats);
+        RT_LAUNCH((render_sorted_kernel<true>), grid, block, 0, st, sc, cam, a, accum, dstats);
       else
-        hipLaunchKernelGGL((render_sorted_kernel<false>), grid, block, 0, st, sc, cam, a, accum, dstats);
+        RT_LAUNCH((render_sorted_kernel<false>), grid, block, 0, st, sc, cam, a, accum, dstats);
       return hipGetLastError();
     }
     if (stats)
-      hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_LINEAR>), grid, block, 0, st, sc, cam, a,
+      RT_LAUNCH((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_LINEAR>), grid, block, 0, st, sc, cam, a,
                          accum, dstats);
     else
-      hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_LINEAR>), grid, block, 0, st, sc, cam, a,
+      RT_LAUNCH((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_LINEAR>), grid, block, 0, st, sc, cam, a,
                          accum, dstats);
     return hipGetLastError();
   }
@@ -64,16 +76,16 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
     static const bool no_refill = getenv("RT_ORDERED_NO_REFILL") != nullptr;
     if (!no_refill) {
       if (stats)
-        hipLaunchKernelGGL((render_refill_kernel<true>), grid, block, lds2, st, sc, cam, a, accum, dstats);
+        RT_LAUNCH((render_refill_kernel<true>), grid, block, lds2, st, sc, cam, a, accum, dstats);
       else
-        hipLaunchKernelGGL((render_refill_kernel<false>), grid, block, lds2, st, sc, cam, a, accum, dstats);
+        RT_LAUNCH((render_refill_kernel<false>), grid, block, lds2, st, sc, cam, a, accum, dstats);
       return hipGetLastError();
     }
     if (stats)
-      hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_ORDERED>), grid, block, lds2, st, sc, cam,
+      RT_LAUNCH((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_ORDERED>), grid, block, lds2, st, sc, cam,
                          a, accum, dstats);
     else
-      hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_ORDERED>), grid, block, lds2, st, sc, cam,
+      RT_LAUNCH((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_ORDERED>), grid, block, lds2, st, sc, cam,
                          a, accum, dstats);
     return hipGetLastError();
   }
@@ -84,19 +96,19 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   constexpr bool F64 = sizeof(RT_REAL) == 8;
   if (F64 || sc.has_noise) {
     if (stats)
-      hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE, true>), grid, block, lds, st, sc,
+      RT_LAUNCH((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE, true>), grid, block, lds, st, sc,
                          cam, a, accum, dstats);
     else
-      hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_REFERENCE, true>), grid, block, lds, st, sc,
+      RT_LAUNCH((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_REFERENCE, true>), grid, block, lds, st, sc,
                          cam, a, accum, dstats);
     return hipGetLastError();
   }
   if constexpr (!F64) {
     if (stats)
-      hipLaunchKernelGGL((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
+      RT_LAUNCH((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
                          accum, dstats);
     else
-      hipLaunchKernelGGL((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
+      RT_LAUNCH((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
                          accum, dstats);
   }
   return hipGetLastError();
@@ -110,17 +122,17 @@ hipError_t RT_CAT(launch_primary_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, cons
   size_t lds = (size_t)shape.stack_depth * BLOCK * sizeof(uint32_t);
 #if RT_HAS_LINEAR
   if (shape.trav == TRAV_ORDERED) {
-    hipLaunchKernelGGL((primary_kernel<RT_REAL, TRAV_ORDERED>), grid, block, lds + lds / 2, st, sc, cam, width, height, seed,
+    RT_LAUNCH((primary_kernel<RT_REAL, TRAV_ORDERED>), grid, block, lds + lds / 2, st, sc, cam, width, height, seed,
                        time, prim_id, t, normal, uv, front_face, shape.stack_depth);
     return hipGetLastError();
   }
   if (shape.trav == TRAV_LINEAR) {
-    hipLaunchKernelGGL((primary_kernel<RT_REAL, TRAV_LINEAR>), grid, block, lds, st, sc, cam, width, height, seed, time,
+    RT_LAUNCH((primary_kernel<RT_REAL, TRAV_LINEAR>), grid, block, lds, st, sc, cam, width, height, seed, time,
                        prim_id, t, normal, uv, front_face, shape.stack_depth);
     return hipGetLastError();
   }
 #endif
-  hipLaunchKernelGGL((primary_kernel<RT_REAL, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, width, height, seed, time,
+  RT_LAUNCH((primary_kernel<RT_REAL, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, width, height, seed, time,
                      prim_id, t, normal, uv, front_face, shape.stack_depth);
   return hipGetLastError();
 }
@@ -135,13 +147,13 @@ hipError_t launch_primary_audited_f32(const SceneView<float>& sc, const SceneVie
   const size_t lds_ref = (size_t)shape.ref_stack_depth * BLOCK * sizeof(uint32_t);
   const size_t lds_own = (size_t)shape.stack_depth * BLOCK * sizeof(uint32_t);
   if (shape.trav == TRAV_ORDERED) {
-    hipLaunchKernelGGL((primary_f32_kernel<TRAV_ORDERED>), grid, block, std::max(lds_ref, lds_own + lds_own / 2), st, sc, sc64,
+    RT_LAUNCH((primary_f32_kernel<TRAV_ORDERED>), grid, block, std::max(lds_ref, lds_own + lds_own / 2), st, sc, sc64,
                        cam64, width, height, seed, time, prim_id, t, normal, uv, front_face, unsure, shape.stack_depth);
   } else if (shape.trav == TRAV_LINEAR) {
-    hipLaunchKernelGGL((primary_f32_kernel<TRAV_LINEAR>), grid, block, lds_ref, st, sc, sc64, cam64, width, height, seed, time,
+    RT_LAUNCH((primary_f32_kernel<TRAV_LINEAR>), grid, block, lds_ref, st, sc, sc64, cam64, width, height, seed, time,
                        prim_id, t, normal, uv, front_face, unsure, shape.stack_depth);
   } else {
-    hipLaunchKernelGGL((primary_f32_kernel<TRAV_REFERENCE>), grid, block, lds_ref, st, sc, sc64, cam64, width, height, seed,
+    RT_LAUNCH((primary_f32_kernel<TRAV_REFERENCE>), grid, block, lds_ref, st, sc, sc64, cam64, width, height, seed,
                        time, prim_id, t, normal, uv, front_face, unsure, shape.stack_depth);
   }
   return hipGetLastError();
@@ -149,7 +161,7 @@ hipError_t launch_primary_audited_f32(const SceneView<float>& sc, const SceneVie
 #endif
 #if RT_HAS_LINEAR
 hipError_t launch_wf_init(const CameraView<float>& cam, const WfArgs& a, const WfPool& pool, WfCounters* ctr, hipStream_t st) {
-  hipLaunchKernelGGL(wf_init_kernel, dim3((pool.n_slots + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, cam, a, pool, ctr);
+  RT_LAUNCH(wf_init_kernel, dim3((pool.n_slots + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, cam, a, pool, ctr);
   return hipGetLastError();
 }
 hipError_t launch_wf_iteration(const SceneView<float>& sc, const CameraView<float>& cam, const WfArgs& a, const WfPool& pool,
@@ -159,11 +171,11 @@ hipError_t launch_wf_iteration(const SceneView<float>& sc, const CameraView<floa
   const size_t lds2 = lds + lds / 2;  // 32-bit refs + 16-bit entry distances
   const dim3 shade_grid((pool.n_slots + BLOCK - 1) / BLOCK);
   if (stats) {
-    hipLaunchKernelGGL((wf_trace_kernel<true>), dim3(trace_blocks), dim3(BLOCK), lds2, st, sc, a, pool, ctr, parity, dstats);
-    hipLaunchKernelGGL((wf_shade_kernel<true>), shade_grid, dim3(BLOCK), 0, st, sc, cam, a, pool, ctr, parity, accum, dstats);
+    RT_LAUNCH((wf_trace_kernel<true>), dim3(trace_blocks), dim3(BLOCK), lds2, st, sc, a, pool, ctr, parity, dstats);
+    RT_LAUNCH((wf_shade_kernel<true>), shade_grid, dim3(BLOCK), 0, st, sc, cam, a, pool, ctr, parity, accum, dstats);
   } else {
-    hipLaunchKernelGGL((wf_trace_kernel<false>), dim3(trace_blocks), dim3(BLOCK), lds2, st, sc, a, pool, ctr, parity, dstats);
-    hipLaunchKernelGGL((wf_shade_kernel<false>), shade_grid, dim3(BLOCK), 0, st, sc, cam, a, pool, ctr, parity, accum, dstats);
+    RT_LAUNCH((wf_trace_kernel<false>), dim3(trace_blocks), dim3(BLOCK), lds2, st, sc, a, pool, ctr, parity, dstats);
+    RT_LAUNCH((wf_shade_kernel<false>), shade_grid, dim3(BLOCK), 0, st, sc, cam, a, pool, ctr, parity, accum, dstats);
   }
   return hipGetLastError();
 }
@@ -176,19 +188,19 @@ hipError_t launch_primary_fix_f64(const SceneView<double>& sc, const CameraView<
                                   uint64_t seed, double time, const uint8_t* unsure, uint32_t* prim_id, float* t, float* normal,
                                   float* uv, uint8_t* front_face, uint32_t ref_stack_depth, hipStream_t st) {
   const uint32_t tiles = ((width + 15) / 16) * ((height + 15) / 16);
-  hipLaunchKernelGGL(primary_fix_kernel, dim3(tiles), dim3(BLOCK), (size_t)ref_stack_depth * BLOCK * sizeof(uint32_t), st, sc, cam,
+  RT_LAUNCH(primary_fix_kernel, dim3(tiles), dim3(BLOCK), (size_t)ref_stack_depth * BLOCK * sizeof(uint32_t), st, sc, cam,
                      width, height, seed, time, unsure, prim_id, t, normal, uv, front_face);
   return hipGetLastError();
 }
 #endif
 
 hipError_t RT_CAT(launch_kat_sphere_uv_, RT_SUFFIX)(uint32_t n, const double* p, double* uv, hipStream_t st) {
-  hipLaunchKernelGGL((kat_sphere_uv_kernel<RT_REAL>), dim3((n + 63) / 64), dim3(64), 0, st, n, p, uv);
+  RT_LAUNCH((kat_sphere_uv_kernel<RT_REAL>), dim3((n + 63) / 64), dim3(64), 0, st, n, p, uv);
   return hipGetLastError();
 }
 hipError_t RT_CAT(launch_kat_rotate_, RT_SUFFIX)(uint32_t n, const double* angle, const double* axis,
                                                  const double* v, double* out, hipStream_t st) {
-  hipLaunchKernelGGL((kat_rotate_kernel<RT_REAL>), dim3((n + 63) / 64), dim3(64), 0, st, n, angle, axis, v, out);
+  RT_LAUNCH((kat_rotate_kernel<RT_REAL>), dim3((n + 63) / 64), dim3(64), 0, st, n, angle, axis, v, out);
   return hipGetLastError();
 }
 
@@ -197,19 +209,19 @@ hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(tonemap_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, accum, n, inv_spp, out);
+  RT_LAUNCH(tonemap_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, accum, n, inv_spp, out);
   return hipGetLastError();
 }
-hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, hipStream_t st) {
+hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, uint32_t n_src, hipStream_t st) {
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(accum_add_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, dst, src, n);
+  RT_LAUNCH(accum_add_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, dst, src, n, n_src);
   return hipGetLastError();
 }
 hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, int path_stream, uint32_t* out,
                              hipStream_t st) {
-  hipLaunchKernelGGL(kat_philox_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, ctr, key, path_stream, out);
+  RT_LAUNCH(kat_philox_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, ctr, key, path_stream, out);
   return hipGetLastError();
 }
 #endif

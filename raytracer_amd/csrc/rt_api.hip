@@ -36,7 +36,10 @@ int fail(int code, const char* fmt, ...) {
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
     hipError_t e_ = (expr);                                                                    \
-    if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    if (e_ != hipSuccess) {                                                                    \
+      (void)hipGetLastError(); /* reported here: do not leave it for a later launch to find */ \
+      return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                  \
+    }                                                                                          \
   } while (0)
 
 // f64 -> device precision.  Box bounds round OUTWARD in f32 so that a ray that passes the
@@ -885,6 +888,10 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   // leaf — measured: shift 1 is +2 % on random_scene / final_scene / 1 M spheres but -8 % at 20 k
   static const char* ls = getenv("RT_LEAF_SHIFT");  // tuning override
   sh.leaf_shift = ls ? (uint32_t)std::min(5, std::max(0, atoi(ls))) : (n_nodes <= 4096 || n_nodes > 65536) ? 1u : 2u;
+  static const char* xc = getenv("RT_XCD_CHUNK");
+  sh.xcd_chunk = xc ? (uint32_t)std::max(0, atoi(xc)) : 1u;
+  static const char* tb = getenv("RT_TILE_BAND");
+  sh.tile_band = tb ? (uint32_t)std::max(1, atoi(tb)) : 1u;  // measured: bands of 2..16 rows are no better than rows
   uint32_t waves = sh.tiles * 4;
   static const char* tw = getenv("RT_TARGET_WAVES");  // tuning override
   // The refill kernel (ordered walk) hands a wave's jobs to whichever lane is free, so its waves end together whatever
@@ -894,6 +901,14 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   const uint32_t target = tw ? (uint32_t)std::max(1, atoi(tw)) : (sh.trav == 2 ? 2u * TARGET_WAVES : TARGET_WAVES);
   uint32_t splits = waves >= target ? 1 : (target + waves - 1) / waves;
   if (sh.trav == 2) splits = std::min(splits, std::max(1u, n_samples / 6u));
+  static const char* fs = getenv("RT_SPLITS");  // tuning override
+  if (sh.trav == 2 && sh.xcd_chunk == 1 && splits >= 5) {
+    // a multiple of 8, so that block_slot can give every XCD whole splits (mode 1)
+    const uint32_t up = (splits + 7u) / 8u * 8u;
+    splits = up <= std::max(1u, n_samples / 4u) ? up : splits / 8u * 8u;
+    if (splits == 0) splits = std::min(8u, n_samples);
+  }
+  if (fs) splits = (uint32_t)std::max(1, atoi(fs));
   sh.splits = std::max(1u, std::min(splits, n_samples));
   // Leaf-list scenes: persistent workers drawing (8x8 tile, sample range) units from a global counter
   // (render_persist_kernel).  Off for max_depth 0 (handled by render_kernel) and with RT_LINEAR_NO_PERSIST (A/B).
@@ -1293,75 +1308,183 @@ int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, const rt_params*
                                  RT_NOALLOC_MAX_LAUNCHES);
 }
 
-// One host thread per device (rayon's "shared immutable scene, independent workers" model,
-// main.rs:157-169, lifted from cores to GPUs): device g renders samples [g*spp/G, (g+1)*spp/G) of
-// every pixel into its own HBM accumulator; the shards are then summed on devices[0].  Every peer
-// has its own xGMI link to devices[0], so the G-1 peer copies run in parallel, one per link; the
-// result is needed on ONE device (it goes to the host), so this is a reduce, not an all-reduce —
+// ---- one process, G devices -----------------------------------------------------------------------------------------
+// rayon's "shared immutable scene, independent workers" model (main.rs:157-169) lifted from cores to GPUs.  An rt_multi
+// keeps what does not change between renders: one device copy of the scene per entry of `devices`, one accumulator and
+// one stream per entry, and on devices[0] a staging area of G-1 images.  A render: one host thread per entry enqueues
+// its sample shard on its own stream, then — on that same stream, so it starts the moment the shard is done, whatever
+// the other devices are doing — a peer copy of the shard into ITS slot of the staging area (every peer has its own
+// xGMI link to devices[0]; the G-1 copies overlap), and records an event.  devices[0]'s stream waits for the G-1 events,
+// ONE kernel adds the G-1 slots to devices[0]'s own shard in shard order, and the image goes to the host; the only host
+// wait is the final one.  The result is needed on one device, so this is a reduce onto devices[0], not an all-reduce;
 // the process-per-GPU path (raytracer_amd/distributed.py) is the one that uses RCCL.
+struct rt_multi {
+  std::vector<int> devices;
+  std::vector<rt_scene*> scenes;
+  std::vector<float*> accum;  // per entry, on its device: `capacity` floats
+  std::vector<hipStream_t> streams;
+  std::vector<hipEvent_t> done;
+  float* staging = nullptr;  // on devices[0]: (G-1) x capacity floats
+  size_t capacity = 0;
+};
+
+void rt_multi_shard(uint64_t spp, uint32_t g, uint32_t n_dev, uint64_t* first, uint64_t* count) {
+  // [g*spp/G, (g+1)*spp/G): contiguous, disjoint, covers [0, spp) for every G; sizes differ by at most one
+  const uint64_t lo = n_dev ? spp * (uint64_t)g / (uint64_t)n_dev : 0;
+  const uint64_t hi = n_dev ? spp * ((uint64_t)g + 1) / (uint64_t)n_dev : 0;
+  if (first) *first = lo;
+  if (count) *count = hi - lo;
+}
+
+void rt_multi_destroy(rt_multi* m) {
+  if (!m) return;
+  for (size_t g = 0; g < m->devices.size(); ++g) {
+    if (hipSetDevice(m->devices[g]) == hipSuccess) {
+      if (g < m->streams.size() && m->streams[g]) (void)hipStreamSynchronize(m->streams[g]);
+      if (g < m->accum.size() && m->accum[g]) (void)hipFree(m->accum[g]);
+      if (g < m->done.size() && m->done[g]) (void)hipEventDestroy(m->done[g]);
+      if (g < m->streams.size() && m->streams[g]) (void)hipStreamDestroy(m->streams[g]);
+      if (g == 0 && m->staging) (void)hipFree(m->staging);
+    }
+    if (g < m->scenes.size()) rt_scene_destroy(m->scenes[g]);
+  }
+  delete m;
+}
+
+int rt_multi_create(int n_dev, const int* devices, const rt_scene_desc* desc, rt_multi** out) {
+  if (!out) return fail(RT_ERR_BAD_ARG, "rt_multi_create: null out");
+  *out = nullptr;
+  if (n_dev < 1 || !devices || !desc) return fail(RT_ERR_BAD_ARG, "rt_multi_create: bad argument");
+  if (n_dev > 64) return fail(RT_ERR_BAD_ARG, "rt_multi_create: at most 64 devices");
+  rt_multi* m = new rt_multi;
+  const size_t G = (size_t)n_dev;
+  m->devices.assign(devices, devices + n_dev);
+  m->scenes.assign(G, nullptr);
+  m->accum.assign(G, nullptr);
+  m->streams.assign(G, nullptr);
+  m->done.assign(G, nullptr);
+  std::vector<int> rcs(G, RT_OK);
+  std::vector<std::string> errs(G);
+  auto work = [&](size_t g) {  // the G scene uploads (tree builds included) run side by side
+    auto bail = [&](int rc) {
+      rcs[g] = rc;
+      errs[g] = g_err;
+    };
+    if (int rc = rt_scene_create(m->devices[g], desc, &m->scenes[g])) return bail(rc);
+    auto hip_try = [&](hipError_t e, const char* what) {
+      if (e != hipSuccess) bail(fail(RT_ERR_HIP, "rt_multi_create: %s: %s", what, hipGetErrorString(e)));
+      return e == hipSuccess;
+    };
+    if (!hip_try(hipSetDevice(m->devices[g]), "hipSetDevice")) return;
+    if (!hip_try(hipStreamCreateWithFlags(&m->streams[g], hipStreamNonBlocking), "hipStreamCreate")) return;
+    if (!hip_try(hipEventCreateWithFlags(&m->done[g], hipEventDisableTiming), "hipEventCreate")) return;
+    if (g > 0 && m->devices[g] != m->devices[0]) {
+      // direct xGMI copies into devices[0]'s staging area; without peer access the runtime stages through the host
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, m->devices[g], m->devices[0]) == hipSuccess && can) {
+        hipError_t e = hipDeviceEnablePeerAccess(m->devices[0], 0);
+        if (e != hipSuccess) (void)hipGetLastError();  // already enabled (an earlier rt_multi, or the caller): fine
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (size_t g = 1; g < G; ++g) pool.emplace_back(work, g);
+  work(0);
+  for (auto& t : pool) t.join();
+  for (size_t g = 0; g < G; ++g)
+    if (rcs[g] != RT_OK) {
+      const int rc = fail(rcs[g], "device %d: %s", m->devices[g], errs[g].c_str());
+      rt_multi_destroy(m);
+      return rc;
+    }
+  *out = m;
+  return RT_OK;
+}
+
+static int multi_reserve(rt_multi* m, size_t n_floats) {
+  if (n_floats <= m->capacity) return RT_OK;
+  const size_t G = m->devices.size();
+  const size_t bytes = std::max<size_t>(n_floats * sizeof(float), 16);
+  for (size_t g = 0; g < G; ++g) {
+    HIP_TRY(hipSetDevice(m->devices[g]));
+    HIP_TRY(hipStreamSynchronize(m->streams[g]));
+    if (m->accum[g]) (void)hipFree(m->accum[g]);
+    m->accum[g] = nullptr;
+    m->capacity = 0;
+    HIP_TRY(hipMalloc((void**)&m->accum[g], bytes));
+    if (g == 0) {
+      if (m->staging) (void)hipFree(m->staging);
+      m->staging = nullptr;
+      if (G > 1) HIP_TRY(hipMalloc((void**)&m->staging, bytes * (G - 1)));
+    }
+  }
+  m->capacity = n_floats;
+  return RT_OK;
+}
+
+int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, float* accum, rt_stats* per_dev) {
+  if (!m || !p || !accum) return fail(RT_ERR_BAD_ARG, "rt_multi_render: null argument");
+  if (int rc = check_camera(cam)) return rc;
+  if (int rc = check_params(p, "rt_multi_render")) return rc;  // before any accumulator is sized from them
+  const size_t G = m->devices.size();
+  const size_t n_floats = (size_t)p->width * p->height * 3;
+  if (int rc = multi_reserve(m, n_floats)) return rc;
+  std::vector<int> rcs(G, RT_OK);
+  std::vector<std::string> errs(G);
+  auto work = [&](size_t g) {
+    auto bail = [&](int rc) {
+      rcs[g] = rc;
+      errs[g] = g_err;
+    };
+    rt_params q = *p;  // samples [first, first + count) of every pixel: the union of the shards' Philox streams is
+    uint64_t first = 0, count = 0;  // independent of G
+    rt_multi_shard(p->spp, (uint32_t)g, (uint32_t)G, &first, &count);
+    q.spp = (uint32_t)count;
+    q.sample_offset = p->sample_offset + first;
+    // stats == NULL keeps the whole call asynchronous; with per_dev the shard's own thread waits for its counters
+    if (int rc = render_on_device<float>(m->scenes[g], cam, &q, m->accum[g], 0, m->streams[g], per_dev ? &per_dev[g] : nullptr))
+      return bail(rc);
+    hipError_t e = hipSuccess;
+    if (g > 0)
+      e = hipMemcpyPeerAsync(m->staging + (g - 1) * n_floats, m->devices[0], m->accum[g], m->devices[g],
+                             n_floats * sizeof(float), m->streams[g]);
+    if (e == hipSuccess && g > 0) e = hipEventRecord(m->done[g], m->streams[g]);
+    if (e != hipSuccess) bail(fail(RT_ERR_HIP, "rt_multi_render: shard %zu copy: %s", g, hipGetErrorString(e)));
+  };
+  std::vector<std::thread> pool;
+  for (size_t g = 1; g < G; ++g) pool.emplace_back(work, g);
+  work(0);
+  for (auto& t : pool) t.join();
+  int rc = RT_OK;
+  for (size_t g = 0; g < G && rc == RT_OK; ++g)
+    if (rcs[g] != RT_OK) rc = fail(rcs[g], "device %d: %s", m->devices[g], errs[g].c_str());
+  auto hip_ok = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_HIP, "rt_multi_render: %s: %s", what, hipGetErrorString(e));
+    return e == hipSuccess;
+  };
+  if (rc == RT_OK && hip_ok(hipSetDevice(m->devices[0]), "hipSetDevice")) {
+    for (size_t g = 1; g < G && rc == RT_OK; ++g) hip_ok(hipStreamWaitEvent(m->streams[0], m->done[g], 0), "hipStreamWaitEvent");
+    if (rc == RT_OK && G > 1)
+      hip_ok(launch_accum_add(m->accum[0], m->staging, n_floats, (uint32_t)(G - 1), m->streams[0]), "accum_add");
+    if (rc == RT_OK)
+      hip_ok(hipMemcpyAsync(accum, m->accum[0], n_floats * sizeof(float), hipMemcpyDeviceToHost, m->streams[0]), "copy back");
+    if (rc == RT_OK) hip_ok(hipStreamSynchronize(m->streams[0]), "hipStreamSynchronize");
+  }
+  if (rc != RT_OK)  // leave nothing of this call in flight behind an error
+    for (size_t g = 0; g < G; ++g)
+      if (hipSetDevice(m->devices[g]) == hipSuccess) (void)hipStreamSynchronize(m->streams[g]);
+  return rc;
+}
+
 int rt_render_multi(int n_dev, const int* devices, const rt_scene_desc* desc, const rt_camera* cam, const rt_params* p,
                     float* accum, rt_stats* per_dev) {
   if (n_dev < 1 || !devices || !desc || !p || !accum) return fail(RT_ERR_BAD_ARG, "rt_render_multi: bad argument");
   if (int rc = check_camera(cam)) return rc;
-  if (int rc = check_params(p, "rt_render_multi")) return rc;  // before G scenes and G accumulators are built
-  if (n_dev > 64) return fail(RT_ERR_BAD_ARG, "rt_render_multi: at most 64 devices");
-  const size_t n_floats = (size_t)p->width * p->height * 3;
-  struct Shard {
-    rt_scene* scene = nullptr;
-    float* d_accum = nullptr;
-    int rc = RT_OK;
-    std::string err;
-  };
-  std::vector<Shard> shards((size_t)n_dev);
-  auto work = [&](int g) {
-    Shard& sh = shards[(size_t)g];
-    auto bail = [&](int rc) {
-      sh.rc = rc;
-      sh.err = g_err;
-    };
-    if (int rc = rt_scene_create(devices[g], desc, &sh.scene)) return bail(rc);
-    hipError_t e = hipMalloc((void**)&sh.d_accum, std::max<size_t>(n_floats * sizeof(float), 16));
-    if (e != hipSuccess) return bail(fail(RT_ERR_HIP, "rt_render_multi: hipMalloc: %s", hipGetErrorString(e)));
-    rt_params q = *p;  // samples [lo, hi) of every pixel: the union of the shards' Philox streams is
-    const uint64_t lo = (uint64_t)p->spp * (uint64_t)g / (uint64_t)n_dev;        // independent of n_dev
-    const uint64_t hi = (uint64_t)p->spp * (uint64_t)(g + 1) / (uint64_t)n_dev;
-    q.spp = (uint32_t)(hi - lo);
-    q.sample_offset = p->sample_offset + lo;
-    rt_stats local;
-    if (int rc = render_on_device<float>(sh.scene, cam, &q, sh.d_accum, 0, nullptr, per_dev ? &per_dev[g] : &local))
-      return bail(rc);
-  };
-  std::vector<std::thread> pool;
-  for (int g = 1; g < n_dev; ++g) pool.emplace_back(work, g);
-  work(0);
-  for (auto& t : pool) t.join();
-
-  int rc = RT_OK;
-  for (int g = 0; g < n_dev && rc == RT_OK; ++g)
-    if (shards[(size_t)g].rc != RT_OK) rc = fail(shards[(size_t)g].rc, "device %d: %s", devices[g], shards[(size_t)g].err.c_str());
-  // reduce onto devices[0]: peer copy into a staging buffer there, then dst += staging
-  float* staging = nullptr;
-  auto hip_ok = [&](hipError_t e, const char* what) {
-    if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_HIP, "rt_render_multi: %s: %s", what, hipGetErrorString(e));
-    return e == hipSuccess;
-  };
-  if (rc == RT_OK && hip_ok(hipSetDevice(devices[0]), "hipSetDevice")) {
-    if (n_dev > 1) hip_ok(hipMalloc((void**)&staging, std::max<size_t>(n_floats * sizeof(float), 16)), "hipMalloc");
-    for (int g = 1; g < n_dev && rc == RT_OK; ++g) {
-      if (!hip_ok(hipMemcpyPeer(staging, devices[0], shards[(size_t)g].d_accum, devices[g], n_floats * sizeof(float)),
-                  "hipMemcpyPeer"))
-        break;
-      hip_ok(launch_accum_add(shards[0].d_accum, staging, n_floats, nullptr), "accum_add");
-      hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
-    }
-    if (rc == RT_OK) hip_ok(hipMemcpy(accum, shards[0].d_accum, n_floats * sizeof(float), hipMemcpyDeviceToHost), "copy back");
-    if (staging) (void)hipFree(staging);
-  }
-  for (int g = 0; g < n_dev; ++g) {
-    Shard& sh = shards[(size_t)g];
-    if (sh.d_accum && hipSetDevice(devices[g]) == hipSuccess) (void)hipFree(sh.d_accum);
-    rt_scene_destroy(sh.scene);
-  }
+  if (int rc = check_params(p, "rt_render_multi")) return rc;  // before G scenes are built
+  rt_multi* m = nullptr;
+  if (int rc = rt_multi_create(n_dev, devices, desc, &m)) return rc;
+  const int rc = rt_multi_render(m, cam, p, accum, per_dev);
+  rt_multi_destroy(m);
   return rc;
 }
 

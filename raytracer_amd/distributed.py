@@ -12,14 +12,14 @@ import torch.distributed as dist
 
 
 def shard_samples(total_spp, rank, world_size, base_offset=0):
-    """Contiguous split of `total_spp` global sample indices: returns (offset, count) of `rank`.
-    The first total_spp % world_size ranks get one extra sample."""
+    """Contiguous split of `total_spp` global sample indices: returns (offset, count) of `rank`:
+    [rank*total/world, (rank+1)*total/world) in integer division — the rule rt_multi_shard (include/rt.h) applies
+    to the devices of one process, so a job renders the same shards whichever way it is spread."""
     if world_size < 1 or not (0 <= rank < world_size):
         raise ValueError(f"bad rank {rank} of {world_size}")
-    q, r = divmod(int(total_spp), int(world_size))
-    count = q + (1 if rank < r else 0)
-    offset = rank * q + min(rank, r)
-    return base_offset + offset, count
+    lo = int(total_spp) * rank // int(world_size)
+    hi = int(total_spp) * (rank + 1) // int(world_size)
+    return base_offset + lo, hi - lo
 
 
 def allreduce_accum(accum):

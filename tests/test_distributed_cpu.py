@@ -28,6 +28,22 @@ def test_shard_samples_partitions_the_index_range():
         shard_samples(8, 2, 2)
 
 
+def test_rt_multi_shard_is_the_same_partition():
+    """rt_multi_shard (include/rt.h; host arithmetic, no GPU): the in-process multi-device path and the
+    process-per-GPU path cut [0, spp) the same way, also when spp is not a multiple of the device count."""
+    import raytracer_amd as R
+    from raytracer_amd.distributed import shard_samples
+    for total in (0, 1, 5, 7, 8, 100, 4095, 4096, 2**32 - 1):
+        for world in (1, 2, 3, 5, 8, 64):
+            got = [R.multi_shard(total, g, world) for g in range(world)]
+            assert got == [shard_samples(total, g, world) for g in range(world)]
+            assert got[0][0] == 0 and sum(c for _, c in got) == total
+            assert all(got[g][0] + got[g][1] == got[g + 1][0] for g in range(world - 1))
+            assert max(c for _, c in got) - min(c for _, c in got) <= 1
+    assert R.multi_shard(10, 0, 3) == (0, 3) and R.multi_shard(10, 2, 3) == (6, 4)
+    assert R.multi_shard(10, 0, 0) == (0, 0)   # n_dev == 0: empty, not a division by zero
+
+
 def _worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -215,6 +215,36 @@ def test_render_multi_equals_single_render(earthmap):
         R.render_multi(hs, [99], W, W, 4, 5)
 
 
+def test_multi_scene_is_reused_across_renders():
+    """rt_multi_create / rt_multi_render / rt_multi_destroy: the per-device scene copies, accumulators and the
+    staging area outlive a render.  Four entries (the one GPU four times) so that three peer copies land in three
+    staging slots before the one add; renders of growing and shrinking size, with and without the per-shard
+    counters (without them the whole call is asynchronous up to its final wait), a sample count smaller than the
+    number of shards (empty shards), and shard-wise equality with plain renders of rt_multi_shard's ranges."""
+    import raytracer_amd as R
+    hs = R.HostScene(6, 1.0)
+    ds = R.DeviceScene(hs, 0)
+    ms = R.MultiScene(hs, [0, 0, 0, 0])
+    for (w, spp, per_device) in ((32, 9, True), (96, 30, False), (48, 3, True), (96, 30, True)):
+        one, s1 = ds.render(w, w, spp, 50, seed=5, sample_offset=7, stats=True)
+        multi, sm = ms.render(w, w, spp, 50, seed=5, sample_offset=7, stats=True, per_device=per_device)
+        np.testing.assert_allclose(multi, one, rtol=2e-5, atol=1e-5)
+        if per_device:
+            assert sum(s["rays"] for s in sm) == s1["rays"]
+            for g, s in enumerate(sm):
+                first, count = R.multi_shard(spp, g, 4)
+                _, sg = ds.render(w, w, count, 50, seed=5, sample_offset=7 + first, stats=True)
+                assert s["rays"] == sg["rays"]
+    # the sum of the shards' own renders (a shard's pixel sums come from float atomics of several sample units, so
+    # equality is to the last bits, not bitwise)
+    parts = [ds.render(64, 64, R.multi_shard(10, g, 4)[1], 50, seed=2, sample_offset=R.multi_shard(10, g, 4)[0])[0]
+             for g in range(4)]
+    want = ((parts[0] + parts[1]) + parts[2]) + parts[3]
+    got, _ = ms.render(64, 64, 10, 50, seed=2)
+    np.testing.assert_allclose(got, want, rtol=3e-6, atol=1e-6)
+    ms.close()
+
+
 @pytest.mark.parametrize("name", list(SCENES))
 def test_f32_tracks_f64_audit_at_equal_seed(name, earthmap):
     """Same seed, same Philox words: the f32 production kernels and the f64 audit kernel follow the same
