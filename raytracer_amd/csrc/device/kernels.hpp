@@ -468,6 +468,7 @@ struct RenderArgs {
   uint32_t unit_samples;    // render_persist_kernel: samples per (8x8 tile, sample range) unit
   uint32_t wave_tiles_x, wave_tiles, total_units;
   uint32_t leaf_shift;  // refill kernel: run the leaf tests once (walking lanes >> leaf_shift) lanes wait at a leaf
+  uint32_t direct_accum;  // units kernel: no LDS accumulators, finished samples go to the image by float atomics
   uint32_t xcd_chunk;   // refill kernel: block_slot's mode
   uint32_t tile_band;   // refill kernel: band_order's band height in tiles
   uint64_t seed;
@@ -638,6 +639,13 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : (size
 // record, Material::scatter, next ray or next camera sample) and re-enters the loop with them
 // refilled — the lanes still walking keep their state in registers and their stack in LDS.  Same
 // paths, same draws as render_kernel: a lane's vertices are still processed in order.
+#ifdef RT_BLOCK_TRACE
+// Diagnostic build (tools/build_variant.sh trace -DRT_BLOCK_TRACE): per wave {start, end (100 MHz ticks), XCC id, HW id},
+// read back by rt_debug_block_trace.  Not in the product library.
+constexpr uint32_t BLOCK_TRACE_MAX = 1u << 20;
+__device__ uint4 g_block_trace[BLOCK_TRACE_MAX];
+#endif
+
 template <bool STATS>
 __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kernel(SceneView<float> sc, CameraView<float> cam,
                                                                                  RenderArgs a, float* __restrict__ accum,
@@ -664,6 +672,9 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
   // keyed by (pixel, sample), not by the lane that renders it; only the f32 order of a pixel's sample sum changes.
   __shared__ float s_acc[BLOCK / 64][64 * 3];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#ifdef RT_BLOCK_TRACE
+  const uint32_t trace_t0 = (uint32_t)wall_clock64();
+#endif
   uint32_t px, py, my_tile, my_split;
   block_slot(a.xcd_chunk, my_tile, my_split);
   my_tile = band_order(my_tile, (a.width + 15u) / 16u, (a.height + 15u) / 16u, a.tile_band);
@@ -822,6 +833,282 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
       out[2] = az;
     }
   }
+#ifdef RT_BLOCK_TRACE
+  {
+    const uint32_t w = ((blockIdx.y * gridDim.x + blockIdx.x) * (BLOCK / 64)) + wave;
+    if (lane == 0 && w < BLOCK_TRACE_MAX)
+      g_block_trace[w] = make_uint4(trace_t0, (uint32_t)wall_clock64(), __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20),
+                                    __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4));
+  }
+#endif
+  flush_stats(cnt, stats);
+  uint32_t nf = wave_sum(nonfinite);
+  if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&stats->v[ST_NONFINITE], (unsigned long long)nf);
+}
+
+// render_refill_kernel as PERSISTENT waves drawing work UNITS (one 8x8 tile x unit_samples samples = 64 x unit_samples
+// jobs) from a global counter — what trav == 2 launches by default.  Why (measured with the block-trace build, final_scene
+// 1024^2 x 512 spp): with one workgroup per (tile, split) the hardware dispatcher kept only ~3000 of the chip's 5120
+// wave slots filled (4500 once the grid was dealt XCD-wise), a workgroup holds its LDS until its slowest wave is done
+// (13-16 % of the resident wave-time idle), and the launch ends with a tail as long as its longest wave (a third of the
+// run on random_scene 400 x 225 x 100 spp).  Here every wave slot of the chip is taken once, at the start, and a wave
+// whose unit has no jobs left to hand out draws the next unit AT ONCE, while its slower lanes are still on paths of
+// the previous one: two units are open per wave (LDS accumulators s_acc[wave][0/1], a job carries its unit's parity),
+// a unit's sums go to the image (float atomics) when its last job finishes.  The only tail left is the launch's last
+// path.  Same jobs, same Philox streams, same walk and shade code as render_refill_kernel.
+constexpr uint32_t UNITS_LDS_FLOATS = 2 * 192 + 2;  // per wave: two units' pixel sums and pixel origins
+
+template <bool STATS>
+__global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_units_kernel(SceneView<float> sc, CameraView<float> cam,
+                                                                                RenderArgs a, float* __restrict__ accum,
+                                                                                DeviceStats* stats) {
+  using R = float;
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  uint16_t* stack_t = reinterpret_cast<uint16_t*>(lds_stack + a.stack_depth * BLOCK) + threadIdx.x;
+  __shared__ Light<R> s_lights[LDS_MAX_LIGHTS];
+  {
+    const uint32_t n_l = sc.n_lights < LDS_MAX_LIGHTS ? sc.n_lights : LDS_MAX_LIGHTS;
+    constexpr uint32_t LW = sizeof(Light<R>) / 4;
+    for (uint32_t i = threadIdx.x; i < n_l * LW; i += BLOCK)
+      reinterpret_cast<uint32_t*>(s_lights)[i] = reinterpret_cast<const uint32_t*>(sc.lights)[i];
+    __syncthreads();
+  }
+  const Light<R>* lights = sc.n_lights <= LDS_MAX_LIGHTS ? s_lights : sc.lights;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // the wave's LDS accumulators, behind the stacks in dynamic LDS: [2 parities][64 pixels x 3] floats + 2 origins.
+  // a.direct_accum != 0: there are none (the launch would lose a resident workgroup per CU to them — deep trees): every
+  // job is an orphan from the start and adds its sample to the image itself
+  const uint32_t direct = a.direct_accum;  // wave-uniform
+  float* s_acc = reinterpret_cast<float*>(lds_stack + a.stack_depth * BLOCK + a.stack_depth * (BLOCK / 2)) + wave * UNITS_LDS_FLOATS;
+  uint32_t* s_origin = reinterpret_cast<uint32_t*>(s_acc + 2 * 192);  // pixel origin (x | y << 16) of the two open units
+#ifdef RT_BLOCK_TRACE
+  const uint32_t trace_t0 = (uint32_t)wall_clock64();
+#endif
+  if (!direct) {
+#pragma unroll
+    for (uint32_t p = 0; p < 2; ++p) {
+      s_acc[p * 192u + lane] = 0.0f;
+      s_acc[p * 192u + 64 + lane] = 0.0f;
+      s_acc[p * 192u + 128 + lane] = 0.0f;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  Cnt<STATS> cnt;
+  cnt.clear();
+  uint32_t nonfinite = 0;
+  const Vec3<R> background(sc.background[0], sc.background[1], sc.background[2]);
+  // wave-uniform: the unit being handed out (parity cp) and the unfinished-job counts of both open units
+  uint32_t cp = 0, n_jobs = 0, next_job = 0, s0 = 0, tx0 = 0, ty0 = 0;
+  uint32_t remaining[2] = {0, 0};
+  bool exhausted = a.max_depth == 0;  // main.rs:73-75: depth 0 -> black (the host has zeroed the image)
+  bool alive = false, walking = false;
+  uint32_t lp = lane;  // pixel (0..63 within its unit's tile) | unit parity << 6 of the job in flight
+  RayT<R> ray;
+  Vec3<R> thr, L;
+  uint32_t depth_left = 0, slot = 0;
+  Rng rng;
+  rng.init(a.seed, 0, 0);
+  OrderedWalk walk;
+  walk.cur = REF_NONE;
+  walk.sp = 0;
+  walk.best = REF_NONE;
+  walk.closest = 0.0f;
+  walk.a = 0.0f;
+
+  // unit parity p is complete: its sums leave LDS
+  auto flush = [&](uint32_t p) {
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t xy = s_origin[p];
+    const uint32_t fx = (xy & 0xFFFFu) + (lane & 7u), fy = (xy >> 16) + (lane >> 3);
+    if (fx < a.width && fy < a.height) {
+      R* out = accum + 3ull * (fy * a.width + fx);
+      atomicAdd(out + 0, s_acc[p * 192u + 3u * lane + 0u]);
+      atomicAdd(out + 1, s_acc[p * 192u + 3u * lane + 1u]);
+      atomicAdd(out + 2, s_acc[p * 192u + 3u * lane + 2u]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    s_acc[p * 192u + lane] = 0.0f;
+    s_acc[p * 192u + 64 + lane] = 0.0f;
+    s_acc[p * 192u + 128 + lane] = 0.0f;
+    __builtin_amdgcn_wave_barrier();
+  };
+
+#ifdef RT_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
+  for (;;) {
+    RT_STAMP(0);
+    // (1) lanes whose path is over take the next jobs; a unit that is handed out makes room for the next one
+    {
+      bool needy = !alive;
+      for (;;) {
+        const uint64_t m = __ballot(needy);
+        if (m == 0) break;
+        if (next_job >= n_jobs) {
+          if (exhausted) break;
+          if (!direct && remaining[cp ^ 1u] != 0) {
+            // the other slot still has paths in flight (paths that outlast a whole unit): rather than wait for them,
+            // its sums so far leave LDS now and those lanes become ORPHANS (bit 7 of lp) that add their sample to
+            // the image themselves when they finish
+            if (alive && ((lp >> 6) & 1u) == (cp ^ 1u)) lp |= 128u;
+            flush(cp ^ 1u);
+            remaining[cp ^ 1u] = 0;
+          }
+          uint32_t u = 0;
+          if (lane == 0) u = atomicAdd(&stats->unit_counter, 1u);
+          u = __builtin_amdgcn_readfirstlane(u);
+          if (u >= a.total_units) {
+            exhausted = true;
+            break;
+          }
+          cp ^= 1u;
+          // unit u: sample chunk u / wave_tiles of 8x8 tile u % wave_tiles; four consecutive tiles are the quarters of
+          // a 16x16 pixel block (wave_tiles_x of those per row), so that the waves of a workgroup start out as neighbours
+          const uint32_t chunk = u / a.wave_tiles, tile = u - chunk * a.wave_tiles;
+          const uint32_t t16 = tile >> 2, trow = t16 / a.wave_tiles_x;
+          tx0 = (t16 - trow * a.wave_tiles_x) * 16u + (tile & 1u) * 8u;
+          ty0 = trow * 16u + ((tile >> 1) & 1u) * 8u;
+          const uint32_t sb = chunk * a.unit_samples;
+          const uint32_t ns = a.n_samples - sb < a.unit_samples ? a.n_samples - sb : a.unit_samples;
+          s0 = a.sample_begin + sb;
+          n_jobs = 64u * ns;
+          next_job = 0;
+          if (!direct) {
+            remaining[cp] = n_jobs;
+            if (lane == 0) s_origin[cp] = tx0 | (ty0 << 16);
+          }
+        }
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t avail = n_jobs - next_job, asked = (uint32_t)__popcll(m);
+        bool dropped = false;
+        if (needy && rank < avail) {
+          const uint32_t j = next_job + rank;
+          lp = (j & 63u) | (cp << 6) | (direct << 7);
+          const uint32_t jx = tx0 + (j & 7u), jy = ty0 + ((j >> 3) & 7u);
+          if (jx < a.width && jy < a.height) {
+            rng.pixel = jy * a.width + jx;
+            rng.sample = s0 + (j >> 6);
+            rng.begin(0);
+            R ju = rng.next<R>();
+            R jv = rng.next<R>();
+            R u = rdiv((R)jx + ju, (R)(a.width - 1));                  // main.rs:161
+            R v = rdiv((R)(a.height - jy - 1) + jv, (R)(a.height - 1));  // main.rs:162-163
+            ray = camera_ray(cam, u, v, rng);
+            thr = Vec3<R>(1, 1, 1);
+            L = Vec3<R>(0, 0, 0);
+            depth_left = a.max_depth;
+            slot = 1;
+            alive = true;
+            needy = false;
+          } else {
+            dropped = true;  // a tile that straddles the image edge: its outside jobs are over at once (the lane asks again)
+          }
+        }
+        next_job += asked < avail ? asked : avail;
+        const uint32_t n_dropped = (uint32_t)__popcll(__ballot(dropped));
+        if (n_dropped && !direct) {
+          remaining[cp] -= n_dropped;
+          if (remaining[cp] == 0) flush(cp);
+        }
+      }
+    }
+    if (!walking && alive) {
+      rng.begin(slot);
+      cnt.template inc<ST_RAYS>();
+      walking = walk.start(sc, ray);
+    }
+    RT_STAMP(1);
+    const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+    if (n_alive == 0) break;  // nothing in flight and nothing handed out: the counter has run dry
+    // refill once this many of the lanes with a path are idle (a.refill_eighths / 8 of them, at least one)
+    const uint32_t refill_q = (n_alive * a.refill_eighths) >> 3;
+    const uint32_t refill_at = refill_q > 0 ? refill_q : 1u;
+    // (2) as render_refill_kernel
+    for (;;) {
+      const uint32_t n_walking = (uint32_t)__popcll(__ballot(walking));
+      if (n_walking + refill_at <= n_alive) break;
+      const uint32_t leaves_at = (n_walking >> a.leaf_shift) > 0 ? (n_walking >> a.leaf_shift) : 1u;
+      RT_STAMP(2);
+      for (;;) {
+        const bool at_node = walking && !(walk.cur & REF_LEAF);
+        const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node));
+        const uint32_t n_walk_now = (uint32_t)__popcll(__ballot(walking));
+        if (n_node == 0 || n_walk_now - n_node >= leaves_at || n_walk_now + refill_at <= n_alive) break;
+        if (at_node) walking = walk.node_step(sc, ray, R(0.001), stack, stack_t, (uint32_t)BLOCK, cnt);
+      }
+      RT_STAMP(3);
+      if (walking && (walk.cur & REF_LEAF))
+        walking = walk.leaf_step(sc, ray, R(0.001), rng, stack, stack_t, (uint32_t)BLOCK, cnt);
+      RT_STAMP(4);
+    }
+    RT_STAMP(5);
+    // (3) lanes whose walk is over: one vertex of ray_color (main.rs:77-104)
+    bool finished = false;
+    if (!walking && alive) {
+      bool cont;
+      if (walk.best == REF_NONE) {  // main.rs:104
+        cnt.template inc<ST_MISSES>();
+        L = madd(L, thr, background);
+        cont = false;
+      } else {
+        cnt.template inc<ST_CLOSEST>();
+        HitRec<R> h;
+        make_hit_record(sc, walk.best, ray, walk.closest, false, h);
+        const Material<R> mat = sc.materials[h.material];
+        cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
+      }
+      ++slot;
+      --depth_left;
+      if (depth_left == 0 && cont) {  // the next ray_color call would return 0
+        depth_exhausted(L, thr);
+        cont = false;
+      }
+      if (cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
+      if (!cont) {
+        const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
+        if (!fin) ++nonfinite;
+        if (fin && !(lp & 128u)) {
+          float* acc = &s_acc[((lp >> 6) & 1u) * 192u + 3u * (lp & 63u)];
+          atomicAdd(acc + 0, L.x);
+          atomicAdd(acc + 1, L.y);
+          atomicAdd(acc + 2, L.z);
+        } else if (fin) {
+          R* out = accum + 3ull * rng.pixel;
+          atomicAdd(out + 0, L.x);
+          atomicAdd(out + 1, L.y);
+          atomicAdd(out + 2, L.z);
+        }
+        alive = false;
+        finished = !(lp & 128u);  // (an orphan's unit has been closed already)
+      }
+    }
+    {
+      const uint64_t f = __ballot(finished);
+      if (f) {
+        const uint32_t f1 = (uint32_t)__popcll(__ballot(finished && (lp & 64u))), f0 = (uint32_t)__popcll(f) - f1;
+        remaining[0] -= f0;
+        remaining[1] -= f1;
+        if (f0 && remaining[0] == 0) flush(0);
+        if (f1 && remaining[1] == 0) flush(1);
+      }
+    }
+    RT_STAMP(6);
+  }
+#ifdef RT_STAMPS
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&stats->stamp[i], stamp_acc[i]);
+#endif
+#ifdef RT_BLOCK_TRACE
+  {
+    const uint32_t w = blockIdx.x * (BLOCK / 64) + wave;
+    if (lane == 0 && w < BLOCK_TRACE_MAX)
+      g_block_trace[w] = make_uint4(trace_t0, (uint32_t)wall_clock64(), __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20),
+                                    __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4));
+  }
+#endif
   flush_stats(cnt, stats);
   uint32_t nf = wave_sum(nonfinite);
   if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&stats->v[ST_NONFINITE], (unsigned long long)nf);

@@ -18,6 +18,7 @@ struct LaunchShape {
   uint32_t ref_stack_depth = 1;  // ... of the reference's tree (the audit walk of rt_primary_hits always walks that one)
   uint32_t refill_eighths = 2;  // ordered walk: see RenderArgs::refill_eighths
   uint32_t leaf_shift = 2;      // ordered walk: see RenderArgs::leaf_shift
+  uint32_t direct_accum = 0;    // units kernel: see RenderArgs::direct_accum
   uint32_t xcd_chunk = 0;       // refill kernel: see RenderArgs::xcd_chunk
   uint32_t tile_band = 1;       // refill kernel: see RenderArgs::tile_band
   // leaf-list scenes, persistent kernel (render_persist_kernel): 0 = off

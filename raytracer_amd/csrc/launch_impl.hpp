@@ -43,6 +43,7 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   a.wave_tiles = shape.wave_tiles;
   a.total_units = shape.total_units;
   a.leaf_shift = shape.leaf_shift;
+  a.direct_accum = shape.direct_accum;
   a.xcd_chunk = shape.xcd_chunk;
   a.tile_band = shape.tile_band;
 #if RT_HAS_LINEAR
@@ -74,6 +75,14 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   if (shape.trav == TRAV_ORDERED) {
     const size_t lds2 = lds + lds / 2;  // 32-bit refs + 16-bit entry distances
     static const bool no_refill = getenv("RT_ORDERED_NO_REFILL") != nullptr;
+    if (!no_refill && shape.unit_samples > 0) {  // persistent waves, work units from a counter: grid = workers
+      const size_t lds3 = lds2 + (shape.direct_accum ? 0 : (BLOCK / 64) * UNITS_LDS_FLOATS * sizeof(float));
+      if (stats)
+        RT_LAUNCH((render_units_kernel<true>), grid, block, lds3, st, sc, cam, a, accum, dstats);
+      else
+        RT_LAUNCH((render_units_kernel<false>), grid, block, lds3, st, sc, cam, a, accum, dstats);
+      return hipGetLastError();
+    }
     if (!no_refill) {
       if (stats)
         RT_LAUNCH((render_refill_kernel<true>), grid, block, lds2, st, sc, cam, a, accum, dstats);

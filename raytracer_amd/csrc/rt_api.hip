@@ -930,6 +930,34 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
       sh.unit_samples = 0;
     }
   }
+  // Ordered-walk scenes: the same, with the refill kernel's job sharing (render_units_kernel).  RT_REFILL_GRID keeps
+  // the one-workgroup-per-(tile, split) form (A/B).
+  static const bool refill_grid = getenv("RT_REFILL_GRID") != nullptr || getenv("RT_ORDERED_NO_REFILL") != nullptr;
+  if (sh.trav == 2 && !refill_grid && max_depth > 0 && n_samples > 0) {
+    // unit size: 8 samples of a tile amortise a unit's hand-over and flush (final_scene 1024^2 x 512 spp: 2 -> 12.3,
+    // 4 -> 12.7, 8 -> 12.8, 32 -> 12.2 Grays/s), but a short launch needs >= 16 units per wave slot of the chip to end
+    // evenly (random_scene 400 x 225 x 100 spp: 2 -> 8.8, 4 -> 8.3, 8 -> 7.6 Grays/s)
+    const uint64_t jobs = (uint64_t)w * h * n_samples;
+    const uint32_t auto_unit = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(2, jobs / (5120ull * 64ull * 16ull)));
+    sh.unit_samples = std::max(1u, std::min(us ? (uint32_t)std::max(1, atoi(us)) : auto_unit, n_samples));
+    sh.wave_tiles_x = (w + 15) / 16;  // 16x16 pixel blocks per row; a unit's tile is a quarter of one
+    sh.wave_tiles = 4u * sh.wave_tiles_x * ((h + 15) / 16);
+    const uint64_t units = (uint64_t)sh.wave_tiles * ((n_samples + sh.unit_samples - 1) / sh.unit_samples);
+    if (units <= 0xFFF00000ull) {
+      sh.total_units = (uint32_t)units;
+      sh.tiles = (uint32_t)std::min<uint64_t>((units + 3) / 4, 256u * 8u);
+      sh.splits = 1;
+      // LDS per workgroup: the stacks (6 B per entry and lane), the lights, and 6 KiB of accumulators — which are
+      // dropped where they would cost a resident workgroup per CU (160 KiB of LDS, at most 5 workgroups by registers)
+      static const char* da = getenv("RT_UNITS_DIRECT");  // tuning override
+      const size_t stack_bytes = (size_t)sh.stack_depth * 256u * 6u, fixed = 512;
+      const size_t with_acc = std::min<size_t>(5, (160u << 10) / (stack_bytes + fixed + 4u * (2u * 192u + 2u) * 4u));
+      const size_t without = std::min<size_t>(5, (160u << 10) / (stack_bytes + fixed));
+      sh.direct_accum = da ? (atoi(da) != 0) : (without > with_acc);
+    } else {
+      sh.unit_samples = 0;
+    }
+  }
   return sh;
 }
 

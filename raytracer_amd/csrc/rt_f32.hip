@@ -7,3 +7,11 @@
 #endif
 #define RT_DEFINE_COMMON 1
 #include "launch_impl.hpp"
+
+#ifdef RT_BLOCK_TRACE
+extern "C" int rt_debug_block_trace(uint32_t* out, uint32_t n_waves) {
+  if (n_waves > rt::BLOCK_TRACE_MAX) n_waves = rt::BLOCK_TRACE_MAX;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_block_trace), (size_t)n_waves * 16) == hipSuccess ? 0 : 1;
+}
+#endif
