@@ -138,7 +138,7 @@ class Workload:
         d = self.hs.desc
         if "RT_FLAG_FORCE_BVH" in counted_on or d.n_nodes == 0:
             return "render_persist_kernel"
-        return "render_refill_kernel"
+        return "render_units_kernel"
 
 
 def roofline(wl, depth, rays, kernel_ms, launches, workload_key):
