@@ -138,6 +138,7 @@ pub struct RtStats {
 }
 
 pub enum RtScene {}
+pub enum RtMulti {}
 
 extern "C" {
     pub fn rt_scene_create(device: c_int, desc: *const RtSceneDesc, out: *mut *mut RtScene) -> c_int;
@@ -148,6 +149,12 @@ extern "C" {
                             accumulate: c_int, stream: *mut c_void, stats: *mut RtStats) -> c_int;
     pub fn rt_render_multi(n_dev: c_int, devices: *const c_int, desc: *const RtSceneDesc, cam: *const RtCamera,
                            p: *const RtParams, accum_rgb: *mut f32, per_dev: *mut RtStats) -> c_int;
+    // the same with the per-device scene copies kept across renders (an animation, progressive passes)
+    pub fn rt_multi_create(n_dev: c_int, devices: *const c_int, desc: *const RtSceneDesc, out: *mut *mut RtMulti) -> c_int;
+    pub fn rt_multi_render(multi: *mut RtMulti, cam: *const RtCamera, p: *const RtParams, accum_rgb: *mut f32,
+                           per_dev: *mut RtStats) -> c_int;
+    pub fn rt_multi_destroy(multi: *mut RtMulti);
+    pub fn rt_multi_shard(spp: u64, g: u32, n_dev: u32, first: *mut u64, count: *mut u64);
     pub fn rt_primary_hits(scene: *mut RtScene, cam: *const RtCamera, width: u32, height: u32, seed: u64, time: f64,
                            prim_id: *mut u32, t: *mut f32, normal: *mut f32, uv: *mut f32, front_face: *mut u8) -> c_int;
     pub fn rt_tonemap(accum_rgb: *const f32, n_pixels: u64, spp: u64, rgb8: *mut u8);
