@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u  /* 2: rt_scene_desc.light_box, RT_LIGHT_CUBE, RT_MAT_AREA_LIGHT */
 #define RT_MAX_BVH_HEIGHT 63u       /* nodes on a root-to-leaf path: 4 B per level and lane of LDS, 64 KiB per workgroup */
 #define RT_NOALLOC_MAX_LAUNCHES 63u /* rt_render_device_noalloc: kernel launches per call (256 B of static scratch each) */
 
@@ -69,7 +69,10 @@ enum rt_material_tag {  /* material.rs:23-30 */
   RT_MAT_DIELECTRIC = 1,   /* params[0] = ir */
   RT_MAT_METAL = 2,        /* params[0..2] = albedo, params[3] = fuzz */
   RT_MAT_DIFFUSE_LIGHT = 3,
-  RT_MAT_ISOTROPIC = 4
+  RT_MAT_ISOTROPIC = 4,
+  RT_MAT_AREA_LIGHT = 5    /* EXTENSION, no counterpart in the reference: emits its texture on EVERY hit.
+                              DiffuseLight emits only on front faces (material.rs:120) and a Cube's recorded normal
+                              points inward (hittable.rs:234-245), so a DiffuseLight cube is black from outside */
 };
 
 enum rt_texture_tag {   /* texture.rs:7-14 */
@@ -87,7 +90,13 @@ enum rt_texture_tag {   /* texture.rs:7-14 */
 
 enum rt_light_tag {     /* hittable.rs:477-515: only Sphere is importance-sampled */
   RT_LIGHT_SPHERE = 0,  /* light_sphere = centre xyz, radius */
-  RT_LIGHT_OTHER = 1    /* pdf_value = 0, random = (1,0,0)   (hittable.rs:498, 513) */
+  RT_LIGHT_OTHER = 1,   /* pdf_value = 0, random = (1,0,0)   (hittable.rs:498, 513) */
+  RT_LIGHT_CUBE = 2     /* EXTENSION, no counterpart in the reference: an axis-aligned box sampled uniformly over its
+                           surface.  light_box = p0 xyz, p1 xyz (p0 < p1).  random(): three draws — face by area (x
+                           faces, y faces, z faces, low side first), then the two in-face coordinates in axis order;
+                           pdf_value(): sum over the points where the probe ray enters (origin outside) and leaves
+                           the box of distance^2 / (|cos| * surface area).  A reference `lights` entry that is a
+                           Cube is RT_LIGHT_OTHER; a host opts in to this tag explicitly */
 };
 
 enum rt_lights_kind {   /* the fold at main.rs:126-131 */
@@ -156,6 +165,7 @@ typedef struct rt_scene_desc {
   uint32_t n_lights;
   const uint8_t* light_tag;       /* rt_light_tag */
   const double* light_sphere;     /* [n_lights][4] */
+  const double* light_box;        /* [n_lights][6], read for RT_LIGHT_CUBE entries only; may be null if there are none */
 
   double background[3];           /* main.rs:139 */
 } rt_scene_desc;

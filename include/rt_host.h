@@ -21,7 +21,8 @@ typedef struct rth_scene rth_scene; /* a flattened scene + its camera, host memo
 typedef struct rth_scene_opts {
   int32_t scene_id;        /* main.rs:117-124: 0 random, 1 two_spheres, 2 earth, 3 simple_light, 4 cube_scene,
                               other small_scene; plus 6 cornell_box, 7 bvh_stress, 8 final_scene, 9 mixed_scene (parity-test
-                              generator), and the extensions 10 perlin_spheres, 11 final_scene with the Perlin sphere */
+                              generator), and the extensions 10 perlin_spheres, 11 final_scene with the Perlin sphere,
+                              12 cornell_box_area (the ceiling light a box: RT_LIGHT_CUBE + RT_MAT_AREA_LIGHT), 13 area_light_plate */
   int32_t rotate_bbox;     /* -1 scene default, 0 reference (Q3), 1 correct */
   double aspect_ratio;     /* main.rs:41-42 */
   uint64_t scene_seed;     /* scenes.rs:64 uses 5 */

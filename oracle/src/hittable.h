@@ -116,6 +116,7 @@ struct Hittable {
   uint32_t owner_id = NO_OBJECT;  // world-level object this node belongs to (keys the medium draw)
 
   V3 p0, p1;                         // Cube
+  bool area_light = false;           // Cube, EXTENSION: importance-sampled when listed in `lights` (see pdf_value)
   V3 center;                         // Sphere
   V3 center_start, center_end;       // MovingSphere
   double time_start = 0, time_end = 1;
@@ -140,6 +141,7 @@ struct Hittable {
     h.owner_id = owner_id;
     h.p0 = p0;
     h.p1 = p1;
+    h.area_light = area_light;
     h.center = center;
     h.center_start = center_start;
     h.center_end = center_end;
@@ -165,6 +167,13 @@ struct Hittable {
     h.p0 = p0;
     h.p1 = p1;
     h.material = std::move(m);
+    return h;
+  }
+  // EXTENSION (no counterpart in the reference, whose pdf_value / random know only Sphere and List,
+  // hittable.rs:477-515): a Cube that `lights` can importance-sample.  Same geometry and hit() as new_cube.
+  static Hittable new_cube_light(V3 p0, V3 p1, Material m) {
+    Hittable h = new_cube(p0, p1, std::move(m));
+    h.area_light = true;
     return h;
   }
   static Hittable new_sphere(V3 c, double r, Material m) {
@@ -514,6 +523,41 @@ struct Hittable {
         for (const auto& h : list) sum += weight * h.pdf_value(origin, direction, rng);
         return sum;
       }
+      case Cube: {
+        // EXTENSION.  random() below picks a point uniformly on the WHOLE surface (area A), so the density of a
+        // direction is the sum over the surface points it meets — a ray crosses a box's surface where it enters
+        // (if the origin is outside) and where it leaves — of distance^2 / (|cos| A).  With an unnormalised
+        // direction v, the point at parameter t and an axis-aligned face normal e_k:
+        // distance^2 = t^2 |v|^2, |cos| = |v_k| / |v|.  The slab loop is aabb.rs:17-34 with (0, inf), plus the axes.
+        if (!area_light) return 0.0;
+        ORC_COUNT(light_probes);
+        ORC_COUNT(cube_tests);
+        double t_in = 0.0, t_out = INF;
+        int k_in = -1, k_out = -1;
+        for (int i = 0; i < 3; ++i) {
+          double inv_d = 1.0 / direction[i];
+          double t0 = (p0[i] - origin[i]) * inv_d;
+          double t1 = (p1[i] - origin[i]) * inv_d;
+          if (inv_d < 0.0) std::swap(t0, t1);
+          if (t0 > t_in) {
+            t_in = t0;
+            k_in = i;
+          }
+          if (t1 < t_out) {
+            t_out = t1;
+            k_out = i;
+          }
+          if (t_out <= t_in) return 0.0;
+        }
+        ORC_COUNT(cube_hits);
+        const V3 e = p1 - p0;
+        const double area = 2.0 * (e.y * e.z + e.x * e.z + e.x * e.y);
+        const double len2 = sqrlen(direction), len3 = len2 * std::sqrt(len2);
+        double sum = 0.0;
+        if (k_in >= 0) sum += t_in * t_in * len3 / (std::fabs(direction[k_in]) * area);
+        if (k_out >= 0) sum += t_out * t_out * len3 / (std::fabs(direction[k_out]) * area);
+        return sum;
+      }
       default:
         return 0.0;
     }
@@ -531,6 +575,23 @@ struct Hittable {
       case List:
         if (!list.empty()) return list[rng.below((uint32_t)list.size())].random(origin, rng);
         return V3(1.0, 0.0, 0.0);
+      case Cube: {
+        // EXTENSION: a point uniform on the surface — three draws: the face (by area: the two x faces, the two y
+        // faces, the two z faces, low side first), then the two coordinates within it in axis order
+        if (!area_light) return V3(1.0, 0.0, 0.0);
+        const V3 e = p1 - p0;
+        const double ax = e.y * e.z, ay = e.x * e.z, az = e.x * e.y;
+        const double s = rng.next_f64() * (2.0 * (ax + ay + az));
+        const double r1 = rng.next_f64(), r2 = rng.next_f64();
+        V3 p;
+        if (s < 2.0 * ax)
+          p = V3(s < ax ? p0.x : p1.x, p0.y + r1 * e.y, p0.z + r2 * e.z);
+        else if (s < 2.0 * ax + 2.0 * ay)
+          p = V3(p0.x + r1 * e.x, s < 2.0 * ax + ay ? p0.y : p1.y, p0.z + r2 * e.z);
+        else
+          p = V3(p0.x + r1 * e.x, p0.y + r2 * e.y, s < 2.0 * ax + 2.0 * ay + az ? p0.z : p1.z);
+        return p - origin;
+      }
       default:
         return V3(1.0, 0.0, 0.0);
     }

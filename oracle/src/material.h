@@ -208,7 +208,10 @@ inline double reflectance(double cosine, double ref_idx) {
 }
 
 struct Material {
-  enum Kind { Lambertian, Dielectric, Metal, DiffuseLight, Isotropic } kind = Lambertian;
+  // AreaLight: EXTENSION, no counterpart in the reference.  DiffuseLight emits only on front faces
+  // (material.rs:120) and a Cube's recorded normal points inward (hittable.rs:234-245, Q1), so a cube with a
+  // DiffuseLight is black from outside; AreaLight emits on every hit.
+  enum Kind { Lambertian, Dielectric, Metal, DiffuseLight, Isotropic, AreaLight } kind = Lambertian;
   Texture texture;  // Lambertian / DiffuseLight / Isotropic
   double ir = 1.0;  // Dielectric
   V3 albedo;        // Metal
@@ -237,6 +240,12 @@ struct Material {
   static Material diffuse_light(V3 emit) {
     Material m;
     m.kind = DiffuseLight;
+    m.texture = Texture::solid(emit);
+    return m;
+  }
+  static Material area_light(V3 emit) {
+    Material m;
+    m.kind = AreaLight;
     m.texture = Texture::solid(emit);
     return m;
   }
@@ -284,6 +293,7 @@ struct Material {
         return s;
       }
       case DiffuseLight:
+      case AreaLight:
         s.kind = ScatterRecord::None;
         return s;
     }
@@ -302,6 +312,7 @@ struct Material {
   // material.rs:118-125
   V3 emit(const HitRecord& hit) const {
     if (kind == DiffuseLight && hit.front_face) return texture.value(hit.uv, hit.p, hit.normal);
+    if (kind == AreaLight) return texture.value(hit.uv, hit.p, hit.normal);  // extension: two-sided
     return V3();
   }
 };

@@ -214,6 +214,44 @@ inline void cornell_box(SceneDef& s) {
   s.rotate_bbox = RotateBBox::Correct;
 }
 
+// EXTENSION scenes (a Cube as an importance-sampled area light; no counterpart in the reference).
+// 12: the canonical Cornell box — the ceiling light is a thin box, everything else as scene 6.
+inline void cornell_box_area(SceneDef& s) {
+  Material red = Material::lambertian(V3(0.65, 0.05, 0.05));
+  Material white = Material::lambertian(V3(0.73, 0.73, 0.73));
+  Material green = Material::lambertian(V3(0.12, 0.45, 0.15));
+  Material light = Material::area_light(V3(15.0, 15.0, 15.0));
+  s.world.push_back(Hittable::new_cube(V3(555.0, 0.0, 0.0), V3(556.0, 555.0, 555.0), green));
+  s.world.push_back(Hittable::new_cube(V3(-1.0, 0.0, 0.0), V3(0.0, 555.0, 555.0), red));
+  s.world.push_back(Hittable::new_cube(V3(0.0, -1.0, 0.0), V3(555.0, 0.0, 555.0), white));
+  s.world.push_back(Hittable::new_cube(V3(0.0, 555.0, 0.0), V3(555.0, 556.0, 555.0), white));
+  s.world.push_back(Hittable::new_cube(V3(0.0, 0.0, 555.0), V3(555.0, 555.0, 556.0), white));
+  s.world.push_back(Hittable::new_cube_light(V3(213.0, 553.0, 227.0), V3(343.0, 554.0, 332.0), light));
+  s.world.push_back(Hittable::new_translate(
+      Hittable::new_rotate(Hittable::new_cube(V3(0.0, 0.0, 0.0), V3(165.0, 330.0, 165.0), white),
+                           to_radians(-15.0), V3(0.0, 1.0, 0.0)),
+      V3(265.0, 0.0, 295.0)));
+  s.world.push_back(Hittable::new_translate(
+      Hittable::new_rotate(Hittable::new_cube(V3(0.0, 0.0, 0.0), V3(165.0, 165.0, 165.0), white),
+                           to_radians(18.0), V3(0.0, 1.0, 0.0)),
+      V3(130.0, 0.0, 65.0)));
+  s.lights.push_back(Hittable::new_cube_light(V3(213.0, 553.0, 227.0), V3(343.0, 554.0, 332.0), light));
+  s.cam = {V3(278.0, 278.0, -800.0), V3(278.0, 278.0, 0.0), V3(0.0, 1.0, 0.0), 40.0, 0.0, 10.0, 0.0, 1.0};
+  s.background = V3(0.0, 0.0, 0.0);
+  s.rotate_bbox = RotateBBox::Correct;
+}
+// 13: a grey floor under a box light against a black sky — the closed-form check of the extension (the irradiance
+// of a point from a uniformly emitting polygon is Lambert's edge sum; tests/test_area_light.py).
+inline void area_light_plate(SceneDef& s) {
+  s.world.push_back(Hittable::new_cube(V3(-50.0, -1.0, -50.0), V3(50.0, 0.0, 50.0), Material::lambertian(V3(0.5, 0.5, 0.5))));
+  Material light = Material::area_light(V3(4.0, 3.0, 2.0));
+  s.world.push_back(Hittable::new_cube_light(V3(-1.0, 3.0, -1.5), V3(1.0, 3.25, 1.5), light));
+  s.lights.push_back(Hittable::new_cube_light(V3(-1.0, 3.0, -1.5), V3(1.0, 3.25, 1.5), light));
+  s.cam = {V3(0.0, 2.0, -9.0), V3(0.0, 0.0, 0.0), V3(0.0, 1.0, 0.0), 40.0, 0.0, 10.0, 0.0, 1.0};
+  s.background = V3(0.0, 0.0, 0.0);
+  s.rotate_bbox = RotateBBox::Correct;
+}
+
 // C4: ground + n random static spheres, material mix as random_scene; scene stream 0.
 inline void bvh_stress(SceneDef& s, uint64_t seed, uint32_t n) {
   Texture checker = Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9));
@@ -420,6 +458,8 @@ inline SceneDef build_scene_def(const SceneSpec& spec) {
     case 9: mixed_scene(s, spec); break;
     case 10: perlin_spheres(s, spec.scene_seed); break;
     case 11: final_scene(s, spec, true); break;
+    case 12: cornell_box_area(s); break;
+    case 13: area_light_plate(s); break;
     default: small_scene(s); break;
   }
   return s;

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_REF_LEAF = 0x80000000
 RT_REF_NONE = 0xFFFFFFFF
 RT_LEAF_SPHERE, RT_LEAF_MSPHERE, RT_LEAF_CUBE, RT_LEAF_COMPLEX = 0, 1, 2, 3
@@ -42,7 +42,7 @@ class RtSceneDesc(C.Structure):
         ("n_textures", C.c_uint32), ("tex_tag", _u8p), ("tex_color", _f64p), ("tex_odd", _u32p),
         ("tex_even", _u32p), ("tex_texel_offset", _u64p), ("tex_width", _u32p), ("tex_height", _u32p),
         ("n_texel_bytes", C.c_uint64), ("texels", _u8p),
-        ("lights_kind", C.c_uint32), ("n_lights", C.c_uint32), ("light_tag", _u8p), ("light_sphere", _f64p),
+        ("lights_kind", C.c_uint32), ("n_lights", C.c_uint32), ("light_tag", _u8p), ("light_sphere", _f64p), ("light_box", _f64p),
         ("background", C.c_double * 3),
     ]
 

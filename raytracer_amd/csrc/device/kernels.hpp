@@ -169,10 +169,49 @@ RT_DEV float light_pdf_cone(const Light<float>& l, Vec3<float> origin, Vec3<floa
   return light_pdf_cone(light_cone(l, origin), unit_direction, cnt);
 }
 
+// EXTENSION (RT_LIGHT_CUBE, no counterpart in the reference): the density, per solid angle, of "a point uniform on the
+// box's surface" in direction v from `origin`: the sum over the points where the ray enters (origin outside) and leaves
+// the box of distance^2 / (|cos| area) = t^2 |v|^3 / (|v_k| area), k the axis of the face.  The slab loop is
+// aabb.rs:17-34 over (0, inf) with the axes remembered; l.c = p0, l.hi = p1, l.radius = surface area.
 template <typename R, bool STATS>
+RT_DEV R light_pdf_cube(const Light<R>& l, Vec3<R> origin, Vec3<R> v, Cnt<STATS>& cnt) {
+  cnt.template inc<ST_LIGHT_PROBES>();
+  cnt.template inc<ST_CUBE_TESTS>();
+  const R o[3] = {origin.x, origin.y, origin.z}, d[3] = {v.x, v.y, v.z};
+  R t_in = R(0), t_out = Consts<R>::inf, d_in = R(0), d_out = R(0);  // |v_k| of the entry / exit face (0: none)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const R inv_d = rdiv(R(1), d[i]);
+    R t0 = (l.c[i] - o[i]) * inv_d, t1 = (l.hi[i] - o[i]) * inv_d;
+    if (inv_d < R(0)) {
+      const R tmp = t0;
+      t0 = t1;
+      t1 = tmp;
+    }
+    if (t0 > t_in) {
+      t_in = t0;
+      d_in = rabs(d[i]);
+    }
+    if (t1 < t_out) {
+      t_out = t1;
+      d_out = rabs(d[i]);
+    }
+    if (t_out <= t_in) return R(0);
+  }
+  cnt.template inc<ST_CUBE_HITS>();
+  const R len2 = sqrlen(v), len3 = len2 * rroot(len2);
+  R sum = R(0);
+  if (d_in != R(0)) sum += rdiv(t_in * t_in * len3, d_in * l.radius);
+  if (d_out != R(0)) sum += rdiv(t_out * t_out * len3, d_out * l.radius);
+  return sum;
+}
+
+template <typename R, bool STATS, bool EXT = false>
 RT_DEV R lights_pdf(const SceneView<R>& sc, const Light<R>* lights, Vec3<R> origin, Vec3<R> direction,
                     Vec3<R> unit_direction, Cnt<STATS>& cnt) {
   auto one = [&](const Light<R>& l) -> R {
+    if constexpr (EXT)
+      if (l.tag == LIGHT_CUBE) return light_pdf_cube(l, origin, direction, cnt);
     if constexpr (sizeof(R) == 4)
       return light_pdf_cone(l, origin, unit_direction, cnt);
     else
@@ -208,9 +247,10 @@ template <typename R> RT_DEV R reflectance(R cosine, R ref_idx) {
 template <typename R, bool STATS, bool NOISE = false>
 RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material<R>& m, const HitRec<R>& h,
                   RayT<R>& ray, Vec3<R>& thr, Vec3<R>& L, Rng& rng, Cnt<STATS>& cnt) {
-  if (m.tag == MAT_DIFFUSE_LIGHT) {  // scatter -> None: return emitted (main.rs:101)
+  // (NOISE = the extension instantiation: Perlin textures, RT_MAT_AREA_LIGHT, RT_LIGHT_CUBE)
+  if (m.tag == MAT_DIFFUSE_LIGHT || (NOISE && m.tag == MAT_AREA_LIGHT)) {  // scatter -> None: return emitted (main.rs:101)
     cnt.template inc<ST_EMITTER>();
-    if (h.front_face) L = madd(L, thr, material_color<R, NOISE>(sc, m, h));
+    if (h.front_face || (NOISE && m.tag == MAT_AREA_LIGHT)) L = madd(L, thr, material_color<R, NOISE>(sc, m, h));
     return false;
   }
   if (m.tag == MAT_DIELECTRIC) {  // material.rs:66-87; emitted is dropped (main.rs:81-83)
@@ -264,11 +304,29 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
     }
   }
   R cos_theta_max_sample = R(0);
+  Vec3<R> direction(1, 0, 0);
   if (from_light) {
     uint32_t i = 0;
     if (sc.lights_kind == LIGHTS_LIST) i = rng.below(sc.n_lights);  // list.choose()
     const Light<R> l = lights[i];
-    if (l.tag != LIGHT_SPHERE) {
+    if (NOISE && l.tag == LIGHT_CUBE) {
+      // EXTENSION: a point uniform on the box's surface — the face by area (x faces, y faces, z faces, low side
+      // first), then the two in-face coordinates in axis order; three draws
+      no_sample = true;
+      const R ex = l.hi[0] - l.c[0], ey = l.hi[1] - l.c[1], ez = l.hi[2] - l.c[2];
+      const R ax = ey * ez, ay = ex * ez, az = ex * ey;
+      const R sel = rng.next<R>() * (R(2) * (ax + ay + az));
+      const R r1 = rng.next<R>();
+      const R r2 = rng.next<R>();
+      Vec3<R> q;
+      if (sel < R(2) * ax)
+        q = Vec3<R>(sel < ax ? l.c[0] : l.hi[0], l.c[1] + r1 * ey, l.c[2] + r2 * ez);
+      else if (sel < R(2) * ax + R(2) * ay)
+        q = Vec3<R>(l.c[0] + r1 * ex, sel < R(2) * ax + ay ? l.c[1] : l.hi[1], l.c[2] + r2 * ez);
+      else
+        q = Vec3<R>(l.c[0] + r1 * ex, l.c[1] + r2 * ey, sel < R(2) * ax + R(2) * ay + az ? l.c[2] : l.hi[2]);
+      direction = q - h.p;
+    } else if (l.tag != LIGHT_SPHERE) {
       no_sample = true;
     } else {
       bool shared = false;
@@ -290,7 +348,6 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
       }
     }
   }
-  Vec3<R> direction(1, 0, 0);
   if (!no_sample) {
     const ONB<R> uvw = sizeof(R) == 4 ? ONB<R>::from_unit_w(axis) : ONB<R>::from_w(axis);
     const R r1 = rng.next<R>();
@@ -311,7 +368,8 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
   // both are unit already to rounding: the normal as above, the direction as an orthonormal basis
   // applied to (cos phi * radial, sin phi * radial, z) with radial^2 + z^2 = 1.
   const Vec3<R> cos_w = sizeof(R) == 4 ? h.normal : normalize(h.normal);
-  Vec3<R> unit = sizeof(R) == 4 ? direction : normalize(direction);
+  // (f32: a direction towards a point of a box light, or the constant (1,0,0), is not unit by construction)
+  Vec3<R> unit = (sizeof(R) == 4 && !(NOISE && no_sample)) ? direction : normalize(direction);
   R cosine = dot(unit, cos_w);
   R cos_pdf = cosine <= R(0) ? R(0) : rdiv(cosine, Consts<R>::pi);
   R pdf_value;
@@ -325,7 +383,7 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
         shared = true;
       }
     }
-    if (!shared) light_pdf = lights_pdf(sc, lights, h.p, direction, unit, cnt);
+    if (!shared) light_pdf = lights_pdf<R, STATS, NOISE>(sc, lights, h.p, direction, unit, cnt);
     pdf_value += R(0.5) * light_pdf;
     pdf_value += R(0.5) * cos_pdf;
   } else {

@@ -12,9 +12,9 @@ constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
 constexpr uint32_t LEAF_SPHERE = 0, LEAF_MSPHERE = 1, LEAF_CUBE = 2, LEAF_COMPLEX = 3;
 constexpr uint32_t OP_TRANSLATE = 0, OP_ROTATE = 1, OP_MEDIUM = 2;
 constexpr uint32_t MAT_LAMBERTIAN = 0, MAT_DIELECTRIC = 1, MAT_METAL = 2, MAT_DIFFUSE_LIGHT = 3,
-                   MAT_ISOTROPIC = 4;
+                   MAT_ISOTROPIC = 4, MAT_AREA_LIGHT = 5 /* extension */;
 constexpr uint32_t TEX_SOLID = 0, TEX_CHECKER = 1, TEX_IMAGE = 2, TEX_NORMAL = 3, TEX_UV = 4, TEX_NOISE = 5;
-constexpr uint32_t LIGHT_SPHERE = 0, LIGHT_OTHER = 1;
+constexpr uint32_t LIGHT_SPHERE = 0, LIGHT_OTHER = 1, LIGHT_CUBE = 2 /* extension */;
 constexpr uint32_t LIGHTS_NONE = 0, LIGHTS_SINGLE = 1, LIGHTS_LIST = 2;
 
 __host__ __device__ inline uint32_t ref_kind(uint32_t r) { return (r >> 28) & 7u; }
@@ -102,7 +102,8 @@ template <typename R> struct Texture {
 };
 template <typename R> struct Light {
   uint32_t tag, pad;
-  R c[3], radius;
+  R c[3], radius;  // LIGHT_SPHERE: centre, radius; LIGHT_CUBE: p0, total surface area
+  R hi[3], pad2;   // LIGHT_CUBE: p1
 };
 
 template <typename R> struct SceneView {
@@ -125,7 +126,8 @@ template <typename R> struct SceneView {
   const uint32_t* linear_rec;  // n_linear leaf records (LIN_DWORDS each) in BVH left-first DFS order
   uint32_t n_linear;           // 0 = scene not eligible for the leaf-list path
   uint32_t linear_has_media;   // some leaf record carries LINF_MEDIUM
-  uint32_t has_noise;          // some texture is TEX_NOISE (extension): only the reference-order kernel evaluates it
+  uint32_t has_noise;          // the scene uses an EXTENSION (a TEX_NOISE texture, a LIGHT_CUBE light, a MAT_AREA_LIGHT
+                               // material): only the reference-order kernel's extension instantiation carries that code
   uint32_t linear_xf_mask, linear_cube_mask, linear_medium_mask;  // bit k = LINF_* of record k (kernel arguments:
                                                                   // scalar registers, no per-leaf flag read from LDS)
   uint32_t root;

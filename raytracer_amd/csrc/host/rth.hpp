@@ -77,7 +77,7 @@ struct Texture {
 
 // ---- material.rs:23-55 -----------------------------------------------------------------
 struct Material {
-  enum Kind { Lambertian, Dielectric, Metal, DiffuseLight, Isotropic } kind = Lambertian;
+  enum Kind { Lambertian, Dielectric, Metal, DiffuseLight, Isotropic, AreaLight } kind = Lambertian;  // AreaLight: extension
   Texture texture;
   double ir = 1.0;
   Color albedo;
@@ -88,6 +88,7 @@ struct Material {
   static Material new_metal(Color albedo, double fuzz);
   static Material new_diffuse_light(Color emit);
   static Material new_isotropic(Color albedo);
+  static Material new_area_light(Color emit);  // EXTENSION (RT_MAT_AREA_LIGHT): emits on every hit
 };
 
 // ---- hittable.rs:42-157 ----------------------------------------------------------------
@@ -104,8 +105,10 @@ struct Hittable {
   double radius = 0, time_start = 0, time_end = 1;
   Material material;
   std::vector<Wrapper> wrappers;  // outermost first
+  bool area_light = false;        // Cube, EXTENSION: listed in `lights` it is importance-sampled (RT_LIGHT_CUBE)
 
   static Hittable new_cube(Point p0, Point p1, Material m);
+  static Hittable new_cube_light(Point p0, Point p1, Material m);  // EXTENSION: a Cube that `lights` can sample
   static Hittable new_sphere(Point center, double radius, Material m);
   static Hittable new_moving_sphere(Point c0, Point c1, double t0, double t1, double radius, Material m);
   static Hittable new_constant_medium(Hittable boundary, double density, Color color);
@@ -167,7 +170,7 @@ SceneDef scene_by_id(const SceneOpts& o);        // main.rs:117-124 (+ ids 6, 7,
 // The flat scene: owns every array an rt_scene_desc points into.
 struct FlatScene {
   FlatBvh bvh;
-  std::vector<double> sphere, msphere, cube, op_data, mat_params, tex_color, light_sphere;
+  std::vector<double> sphere, msphere, cube, op_data, mat_params, tex_color, light_sphere, light_box;
   std::vector<uint32_t> sphere_material, sphere_object, msphere_material, msphere_object, cube_material, cube_object;
   std::vector<uint32_t> complex_body, complex_op_first, complex_op_count, complex_material, complex_object;
   std::vector<uint8_t> op_tag, mat_tag, tex_tag, light_tag, texels;

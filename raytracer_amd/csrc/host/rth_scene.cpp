@@ -172,6 +172,12 @@ Material Material::new_diffuse_light(Color emit) {
   m.texture = Texture::new_solid(emit);
   return m;
 }
+Material Material::new_area_light(Color emit) {
+  Material m;
+  m.kind = AreaLight;
+  m.texture = Texture::new_solid(emit);
+  return m;
+}
 Material Material::new_isotropic(Color albedo) {
   Material m;
   m.kind = Isotropic;
@@ -186,6 +192,11 @@ Hittable Hittable::new_cube(Point p0, Point p1, Material m) {
   h.a = p0;
   h.b = p1;
   h.material = std::move(m);
+  return h;
+}
+Hittable Hittable::new_cube_light(Point p0, Point p1, Material m) {
+  Hittable h = new_cube(p0, p1, std::move(m));
+  h.area_light = true;
   return h;
 }
 Hittable Hittable::new_sphere(Point center, double radius, Material m) {
@@ -512,6 +523,10 @@ struct Flattener {
         fs.mat_tag[me] = RT_MAT_ISOTROPIC;
         fs.mat_texture[me] = add_texture(m.texture);
         break;
+      case Material::AreaLight:
+        fs.mat_tag[me] = RT_MAT_AREA_LIGHT;
+        fs.mat_texture[me] = add_texture(m.texture);
+        break;
     }
     return me;
   }
@@ -605,11 +620,17 @@ FlatScene flatten(const SceneDef& def, uint64_t bvh_seed, RotateBBox mode) {
   if (!none)
     for (const Hittable& h : l) {
       bool plain_sphere = h.kind == Hittable::Sphere && h.wrappers.empty();  // hittable.rs:479, 504
-      fs.light_tag.push_back(plain_sphere ? RT_LIGHT_SPHERE : RT_LIGHT_OTHER);
+      // extension: a bare Cube built by new_cube_light; any other Cube is the reference's `_` arm
+      bool box_light = h.kind == Hittable::Cube && h.wrappers.empty() && h.area_light;
+      fs.light_tag.push_back(plain_sphere ? RT_LIGHT_SPHERE : (box_light ? RT_LIGHT_CUBE : RT_LIGHT_OTHER));
       if (plain_sphere)
         fs.light_sphere.insert(fs.light_sphere.end(), {h.a[0], h.a[1], h.a[2], h.radius});
       else
         fs.light_sphere.insert(fs.light_sphere.end(), {0.0, 0.0, 0.0, 0.0});
+      if (box_light)
+        fs.light_box.insert(fs.light_box.end(), {h.a[0], h.a[1], h.a[2], h.b[0], h.b[1], h.b[2]});
+      else
+        fs.light_box.insert(fs.light_box.end(), {0.0, 0.0, 0.0, 0.0, 0.0, 0.0});
     }
   return fs;
 }
@@ -662,6 +683,7 @@ rt_scene_desc FlatScene::desc() const {
   d.n_lights = (uint32_t)light_tag.size();
   d.light_tag = light_tag.data();
   d.light_sphere = light_sphere.data();
+  d.light_box = light_box.data();
   for (int i = 0; i < 3; ++i) d.background[i] = background[i];
   return d;
 }

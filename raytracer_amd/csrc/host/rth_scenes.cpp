@@ -136,6 +136,28 @@ SceneDef cornell_box() {
   return s;
 }
 
+// EXTENSION scenes (a Cube as an importance-sampled area light; no counterpart in the reference)
+SceneDef cornell_box_area() {  // 12: the canonical Cornell box, the ceiling light a thin box
+  SceneDef s = cornell_box();
+  const Material lamp = Material::new_area_light(Color(15.0, 15.0, 15.0));
+  const Hittable panel = Hittable::new_cube_light(Point(213.0, 553.0, 227.0), Point(343.0, 554.0, 332.0), lamp);
+  s.world[5] = panel;  // in place of the bulb
+  s.lights.assign(1, panel);
+  return s;
+}
+SceneDef area_light_plate() {  // 13: a grey floor under a box light, black sky: the closed-form check
+  SceneDef s;
+  s.world.push_back(Hittable::new_cube(Point(-50.0, -1.0, -50.0), Point(50.0, 0.0, 50.0), Material::new_lambertian(Color(0.5, 0.5, 0.5))));
+  const Hittable panel =
+      Hittable::new_cube_light(Point(-1.0, 3.0, -1.5), Point(1.0, 3.25, 1.5), Material::new_area_light(Color(4.0, 3.0, 2.0)));
+  s.world.push_back(panel);
+  s.lights.push_back(panel);
+  s.cam = CameraSpec{Point(0.0, 2.0, -9.0), Point(0.0, 0.0, 0.0), Vector(0.0, 1.0, 0.0), 40.0, 0.0, 10.0, 0.0, 1.0};
+  s.background = Color(0.0, 0.0, 0.0);
+  s.rotate_bbox = RotateBBox::Correct;
+  return s;
+}
+
 SceneDef bvh_stress(uint64_t seed, uint32_t n) {
   SceneDef s = with_reference_view();
   s.world.reserve((size_t)n + 1);
@@ -327,6 +349,8 @@ SceneDef scene_by_id(const SceneOpts& o) {
     case 9: return mixed_scene(o);
     case 10: return perlin_spheres(o.scene_seed);
     case 11: return final_scene(o, true);
+    case 12: return cornell_box_area();
+    case 13: return area_light_plate();
     default: return small_scene();  // main.rs:123
   }
 }

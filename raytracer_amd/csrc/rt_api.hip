@@ -360,6 +360,15 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
     lights[i].tag = d.light_tag[i];
     for (int k = 0; k < 3; ++k) lights[i].c[k] = conv<R>(d.light_sphere[4 * (size_t)i + k]);
     lights[i].radius = conv<R>(d.light_sphere[4 * (size_t)i + 3]);
+    if (d.light_tag[i] == RT_LIGHT_CUBE) {  // extension: p0, p1 and the surface area (in f64, rounded once)
+      const double* b = d.light_box + 6 * (size_t)i;
+      const double ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+      for (int k = 0; k < 3; ++k) {
+        lights[i].c[k] = conv<R>(b[k]);
+        lights[i].hi[k] = conv<R>(b[3 + k]);
+      }
+      lights[i].radius = conv<R>(2.0 * (ey * ez + ex * ez + ex * ey));
+    }
   }
   hipError_t e;
 #define UP(vec, field) \
@@ -433,6 +442,10 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
   s.view.has_noise = 0;
   for (uint32_t i = 0; i < d.n_textures; ++i)
     if (d.tex_tag[i] == RT_TEX_NOISE) s.view.has_noise = 1;
+  for (uint32_t i = 0; i < d.n_materials; ++i)
+    if (d.mat_tag[i] == RT_MAT_AREA_LIGHT) s.view.has_noise = 1;
+  for (uint32_t i = 0; i < d.n_lights; ++i)
+    if (d.light_tag[i] == RT_LIGHT_CUBE) s.view.has_noise = 1;
   s.view.linear_has_media = 0;
   s.view.linear_xf_mask = s.view.linear_cube_mask = s.view.linear_medium_mask = 0;
   static_assert(LIN_MAX_LEAVES <= 32, "leaf-list flag masks are 32 bits wide");
@@ -654,7 +667,15 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
   NEED(d->lights_kind <= RT_LIGHTS_LIST, "bad lights_kind");
   NEED((d->lights_kind == RT_LIGHTS_NONE) == (d->n_lights == 0), "lights_kind / n_lights mismatch");
   NEED(d->lights_kind != RT_LIGHTS_SINGLE || d->n_lights == 1, "RT_LIGHTS_SINGLE needs exactly one light");
-  for (uint32_t i = 0; i < d->n_lights; ++i) NEED(d->light_tag[i] <= RT_LIGHT_OTHER, "bad light tag");
+  for (uint32_t i = 0; i < d->n_lights; ++i) {
+    NEED(d->light_tag[i] <= RT_LIGHT_CUBE, "bad light tag");
+    if (d->light_tag[i] == RT_LIGHT_CUBE) {
+      NEED(d->light_box, "RT_LIGHT_CUBE without light_box");
+      const double* b = d->light_box + 6 * (size_t)i;
+      NEED(b[0] < b[3] && b[1] < b[4] && b[2] < b[5] && std::isfinite(b[0] + b[1] + b[2] + b[3] + b[4] + b[5]),
+           "RT_LIGHT_CUBE: light_box needs finite p0 < p1");
+    }
+  }
 
   // textures: tags, checker children in range and acyclic (children must have a larger index)
   for (uint32_t i = 0; i < d->n_textures; ++i) {
@@ -673,9 +694,9 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
     }
   }
   for (uint32_t i = 0; i < d->n_materials; ++i) {
-    NEED(d->mat_tag[i] <= RT_MAT_ISOTROPIC, "bad material tag");
+    NEED(d->mat_tag[i] <= RT_MAT_AREA_LIGHT, "bad material tag");
     bool textured = d->mat_tag[i] == RT_MAT_LAMBERTIAN || d->mat_tag[i] == RT_MAT_DIFFUSE_LIGHT ||
-                    d->mat_tag[i] == RT_MAT_ISOTROPIC;
+                    d->mat_tag[i] == RT_MAT_ISOTROPIC || d->mat_tag[i] == RT_MAT_AREA_LIGHT;
     if (textured) NEED(d->mat_texture[i] < d->n_textures, "material texture out of range");
   }
   for (uint32_t i = 0; i < d->n_spheres; ++i) NEED(d->sphere_material[i] < d->n_materials, "sphere material out of range");

@@ -27,6 +27,9 @@ SCENES = {
     # extensions: Perlin noise texture
     "perlin_spheres": (10, 1.5, 0, 5),
     "final_scene_perlin": (11, 1.0, 0, 50),
+    # extensions: a Cube as an importance-sampled area light (RT_LIGHT_CUBE + RT_MAT_AREA_LIGHT)
+    "cornell_box_area": (12, 1.0, 0, 50),
+    "area_light_plate": (13, 1.0, 0, 5),
 }
 
 
