@@ -8,7 +8,7 @@ use image::RgbImage;
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RT_ABI_VERSION: u32 = 1;
+pub const RT_ABI_VERSION: u32 = 2;
 pub const RT_REF_LEAF: u32 = 0x8000_0000;
 pub const RT_REF_NONE: u32 = 0xFFFF_FFFF;
 pub const fn make_leaf(kind: u32, index: u32) -> u32 { RT_REF_LEAF | (kind << 28) | index }
@@ -83,6 +83,7 @@ pub struct RtSceneDesc {
     pub n_lights: u32,
     pub light_tag: *const u8,
     pub light_sphere: *const f64, // [n_lights][4]
+    pub light_box: *const f64,    // [n_lights][6], RT_LIGHT_CUBE (extension) only: null here
     pub background: [f64; 3],
 }
 
@@ -277,6 +278,7 @@ impl FlatScene {
             n_lights: self.light_tag.len() as u32,
             light_tag: self.light_tag.as_ptr(),
             light_sphere: self.light_sphere.as_ptr(),
+            light_box: std::ptr::null(),
             background: self.background,
         }
     }
