@@ -360,3 +360,25 @@ def test_f32_drops_the_samples_that_poison_f64_pixels():
     # tone-mapped: the reference's pixel is 0 where poisoned, the f32 one is a finite colour
     u8_64 = R.tonemap(np.nan_to_num(f64, nan=np.nan).astype(np.float32), spp)
     assert (u8_64[bad64] == 0).all()
+
+
+@pytest.mark.parametrize("size", [(2, 2), (37, 23), (3, 130), (130, 3), (49, 33)])
+@pytest.mark.parametrize("spp", [1, 3, 11])
+def test_units_kernel_on_ragged_images_and_odd_sample_counts(size, spp):
+    """render_units_kernel (persistent waves, 8x8-tile x sample-chunk units, two open units per wave): images that fill
+    no 16x16 block (units whose tile lies partly or wholly outside the image) and sample counts that are no multiple of
+    the unit size must render exactly the reference-order walk's paths — equal ray counts, pixel sums equal to f32
+    summation order — and add on top of an existing accumulator."""
+    import torch
+    import raytracer_amd as R
+    w, h = size
+    hs = R.HostScene(7, w / h, n=3000)
+    ds = R.DeviceScene(hs, 0)
+    a, sa = ds.render(w, h, spp, 50, seed=4, sample_offset=2, stats=True)
+    b, sb = ds.render(w, h, spp, 50, seed=4, sample_offset=2, stats=True, force_bvh=True)
+    assert sa["rays"] == sb["rays"] and sa["nonfinite_samples"] == sb["nonfinite_samples"]
+    fin = np.isfinite(a) & np.isfinite(b)
+    np.testing.assert_allclose(a[fin], b[fin], rtol=3e-5, atol=1e-6)
+    acc = torch.full((h, w, 3), 2.0, dtype=torch.float32, device="cuda:0")
+    ds.render_device(acc.data_ptr(), w, h, spp, 50, seed=4, sample_offset=2, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy()[fin], (a + 2.0)[fin], rtol=3e-5, atol=1e-5)
