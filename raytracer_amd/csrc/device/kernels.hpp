@@ -1128,6 +1128,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_units_kerne
         HitRec<R> h;
         make_hit_record(sc, walk.best, ray, walk.closest, false, h);
         const Material<R> mat = sc.materials[h.material];
+        RT_STAMP(7);
         cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
       }
       ++slot;
