@@ -22,7 +22,9 @@ typedef struct rth_scene_opts {
   int32_t scene_id;        /* main.rs:117-124: 0 random, 1 two_spheres, 2 earth, 3 simple_light, 4 cube_scene,
                               other small_scene; plus 6 cornell_box, 7 bvh_stress, 8 final_scene, 9 mixed_scene (parity-test
                               generator), and the extensions 10 perlin_spheres, 11 final_scene with the Perlin sphere,
-                              12 cornell_box_area (the ceiling light a box: RT_LIGHT_CUBE + RT_MAT_AREA_LIGHT), 13 area_light_plate */
+                              12 cornell_box_area (the ceiling light a box: RT_LIGHT_CUBE + RT_MAT_AREA_LIGHT), 13 area_light_plate;
+                              14 random_scene with its geometry drawn from StdRng::seed_from_u64(scene_seed) like
+                              scenes.rs:64-98 (parity unpinned, see rth_kat_stdrng) */
   int32_t rotate_bbox;     /* -1 scene default, 0 reference (Q3), 1 correct */
   double aspect_ratio;     /* main.rs:41-42 */
   uint64_t scene_seed;     /* scenes.rs:64 uses 5 */
@@ -79,6 +81,13 @@ int rth_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_
 /* Host-side known-answer hooks for the two functions the reference's tests pin. */
 void rth_rotate(double angle_rad, const double axis[3], const double v[3], double out[3]);
 int rth_bvh_axis(uint64_t bvh_seed, uint32_t call);
+/* ... and for the generator of scene 14 (StdRng::seed_from_u64, scenes.rs:64; csrc/host/std_rng.hpp): the ChaCha block
+ * function on a caller-made 16-word state (out = permuted(state) + state; pinned by RFC 7539 2.3.2 at 20 rounds, StdRng
+ * uses 12), one quarter round in place (RFC 7539 2.1.1), and the first n draws of a seeded generator as raw u64 words,
+ * as gen::<f64>() and as gen_range(lo..hi), each from its own copy of the generator.                                  */
+void rth_kat_chacha(const uint32_t state[16], uint32_t rounds, uint32_t out[16]);
+void rth_kat_chacha_quarter(uint32_t abcd[4]);
+void rth_kat_stdrng(uint64_t seed, uint32_t n, uint64_t* words, double* unit, double* ranged, double lo, double hi);
 
 const char* rth_last_error(void);
 

@@ -171,6 +171,17 @@ void orc_philox(const uint32_t* ctr, const uint32_t* key, uint32_t rounds, uint3
   std::memcpy(out, r.v, sizeof(r.v));
 }
 int orc_bvh_axis(uint64_t bvh_seed, uint32_t call) { return bvh_axis(bvh_seed, call); }
+// stdrng.h known-answer hooks: the block function on a caller-made state; StdRng::seed_from_u64 streams
+void orc_chacha_block(const uint32_t* state, uint32_t rounds, uint32_t* out) { chacha_block(state, (int)rounds, out); }
+void orc_chacha_quarter(uint32_t* abcd) { chacha_quarter(abcd[0], abcd[1], abcd[2], abcd[3]); }
+void orc_stdrng_draws(uint64_t seed, uint32_t n, uint64_t* words, double* unit, double* ranged, double lo, double hi) {
+  StdRng a = StdRng::seed_from_u64(seed), b = a, c = a;
+  for (uint32_t i = 0; i < n; ++i) {
+    words[i] = a.next_u64();
+    unit[i] = b.next_f64();
+    ranged[i] = c.range(lo, hi);
+  }
+}
 void orc_scene_draws(uint64_t seed, uint32_t stream, uint32_t n, double* out) {
   Rng r = scene_rng(seed, stream);
   for (uint32_t i = 0; i < n; ++i) out[i] = r.next_f64();

@@ -6,6 +6,7 @@
 // Cornell box, BVH stress, final-scene composition — built only from reference primitives.
 #pragma once
 #include "hittable.h"
+#include "stdrng.h"
 
 namespace orc {
 
@@ -112,11 +113,11 @@ inline void small_scene(SceneDef& s) {
 
 // scenes.rs:55-123.  The seeded StdRng becomes scene stream 0; the unseeded thread_rng
 // behind Vector::random_vector() (Q18) becomes scene stream 1.
-inline void random_scene(SceneDef& s, uint64_t seed) {
+// `rng` stands for scenes.rs:64's StdRng (scene 0: a keyed Philox stream, as north_star prescribes; scene 14: StdRng
+// itself, stdrng.h); `trng` for the unseeded thread_rng behind Vector::random_vector (scenes.rs:77, alias.rs:40-42).
+template <typename Main> inline void random_scene_with(SceneDef& s, Main& rng, Rng& trng) {
   Texture checker = Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9));
   s.world.push_back(Hittable::new_sphere(V3(0.0, -1000.0, 0.0), 1000.0, Material::lambertian_tex(checker)));
-  Rng rng = scene_rng(seed, 0);
-  Rng trng = scene_rng(seed, 1);
   for (int a = -11; a < 11; ++a) {
     for (int b = -11; b < 11; ++b) {
       double choose_mat = rng.next_f64();
@@ -150,6 +151,19 @@ inline void random_scene(SceneDef& s, uint64_t seed) {
   s.world.push_back(Hittable::new_sphere(V3(0.0, 1.0, 0.0), 1.0, Material::dielectric(1.5)));
   s.world.push_back(Hittable::new_sphere(V3(-4.0, 1.0, 0.0), 1.0, Material::lambertian(V3(0.4, 0.2, 0.1))));
   s.world.push_back(Hittable::new_sphere(V3(4.0, 1.0, 0.0), 1.0, Material::metal(V3(0.7, 0.6, 0.5), 0.0)));
+}
+inline void random_scene(SceneDef& s, uint64_t seed) {
+  Rng rng = scene_rng(seed, 0);
+  Rng trng = scene_rng(seed, 1);
+  random_scene_with(s, rng, trng);
+}
+// scene 14: the reference's own geometry — positions, material classes, metal parameters and the moving spheres'
+// second centres from StdRng::seed_from_u64(seed) (scenes.rs:64 uses 5); the Lambertian albedos, which the reference
+// takes from the unseeded thread_rng, from the Philox stream as in scene 0.  Parity unpinned (stdrng.h).
+inline void random_scene_stdrng(SceneDef& s, uint64_t seed) {
+  StdRng rng = StdRng::seed_from_u64(seed);
+  Rng trng = scene_rng(seed, 1);
+  random_scene_with(s, rng, trng);
 }
 
 inline Texture earth_texture(const SceneSpec& spec) {
@@ -460,6 +474,7 @@ inline SceneDef build_scene_def(const SceneSpec& spec) {
     case 11: final_scene(s, spec, true); break;
     case 12: cornell_box_area(s); break;
     case 13: area_light_plate(s); break;
+    case 14: random_scene_stdrng(s, spec.scene_seed); break;
     default: small_scene(s); break;
   }
   return s;

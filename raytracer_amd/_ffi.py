@@ -104,7 +104,8 @@ RT_SYMBOLS = [
 RTH_SYMBOLS = [
     "rth_scene_build", "rth_scene_free", "rth_scene_desc", "rth_scene_camera", "rth_scene_object_count",
     "rth_scene_bvh_calls", "rth_camera_new", "rth_render", "rth_image_height", "rth_write_png", "rth_rotate",
-    "rth_bvh_axis", "rth_texture_from_rgb8_file", "rth_texture_free",
+    "rth_bvh_axis", "rth_texture_from_rgb8_file", "rth_texture_free", "rth_kat_chacha", "rth_kat_chacha_quarter",
+    "rth_kat_stdrng",
     "rth_last_error",
 ]
 
@@ -180,6 +181,12 @@ host.rth_rotate.argtypes = [C.c_double, _p, _p, _p]
 host.rth_rotate.restype = None
 host.rth_bvh_axis.argtypes = [C.c_uint64, C.c_uint32]
 host.rth_bvh_axis.restype = C.c_int
+host.rth_kat_chacha.argtypes = [_p, C.c_uint32, _p]
+host.rth_kat_chacha.restype = None
+host.rth_kat_chacha_quarter.argtypes = [_p]
+host.rth_kat_chacha_quarter.restype = None
+host.rth_kat_stdrng.argtypes = [C.c_uint64, C.c_uint32, _p, _p, _p, C.c_double, C.c_double]
+host.rth_kat_stdrng.restype = None
 
 
 class RtError(RuntimeError):

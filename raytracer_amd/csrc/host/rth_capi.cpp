@@ -10,6 +10,7 @@
 
 #include "../../../include/rt_host.h"
 #include "rth.hpp"
+#include "std_rng.hpp"
 #include "png_write.hpp"
 
 using namespace rth;
@@ -218,5 +219,20 @@ void rth_rotate(double angle_rad, const double axis[3], const double v[3], doubl
   out[2] = r[2];
 }
 int rth_bvh_axis(uint64_t bvh_seed, uint32_t call) { return bvh_axis(bvh_seed, call); }
+void rth_kat_chacha(const uint32_t* state, uint32_t rounds, uint32_t* out) {
+  ChaCha::Words in;
+  std::memcpy(in.data(), state, sizeof(in));
+  const ChaCha::Words r = ChaCha::block(in, rounds);
+  std::memcpy(out, r.data(), sizeof(r));
+}
+void rth_kat_chacha_quarter(uint32_t* abcd) { ChaCha::quarter(abcd[0], abcd[1], abcd[2], abcd[3]); }
+void rth_kat_stdrng(uint64_t seed, uint32_t n, uint64_t* words, double* unit, double* ranged, double lo, double hi) {
+  StdRng a(seed), b(seed), c(seed);
+  for (uint32_t i = 0; i < n; ++i) {
+    words[i] = a.next_u64();
+    unit[i] = b.next_f64();
+    ranged[i] = c.range(lo, hi);
+  }
+}
 
 }  // extern "C"

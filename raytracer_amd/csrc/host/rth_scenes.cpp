@@ -5,6 +5,7 @@
 #include <stdexcept>
 
 #include "rth.hpp"
+#include "std_rng.hpp"
 
 namespace rth {
 
@@ -42,12 +43,12 @@ SceneDef small_scene() {
 
 // Draw stream 0 replaces the seeded StdRng (scenes.rs:64), stream 1 the unseeded thread_rng
 // behind Vector::random_vector() (scenes.rs:77, Q18).
-SceneDef random_scene(uint64_t seed) {
+// `main` = scenes.rs:64's StdRng (scene 0: a keyed Philox stream; scene 14: StdRng itself, std_rng.hpp)
+template <typename Main> static SceneDef random_scene_from(Main& main, Stream& albedo) {
   SceneDef s = with_reference_view();
   s.world.push_back(Hittable::new_sphere(
       Point(0.0, -1000.0, 0.0), 1000.0,
       Material::new_lambertian_with_texture(Texture::new_checker_color(Color(0.2, 0.3, 0.1), Color(0.9, 0.9, 0.9)))));
-  Stream main = scene_stream(seed, 0), albedo = scene_stream(seed, 1);
   for (int a = -11; a < 11; ++a)
     for (int b = -11; b < 11; ++b) {
       const double choose_mat = main.next_f64();
@@ -72,6 +73,17 @@ SceneDef random_scene(uint64_t seed) {
   s.world.push_back(Hittable::new_sphere(Point(-4.0, 1.0, 0.0), 1.0, Material::new_lambertian(Color(0.4, 0.2, 0.1))));
   s.world.push_back(Hittable::new_sphere(Point(4.0, 1.0, 0.0), 1.0, Material::new_metal(Color(0.7, 0.6, 0.5), 0.0)));
   return s;
+}
+SceneDef random_scene(uint64_t seed) {
+  Stream main = scene_stream(seed, 0), albedo = scene_stream(seed, 1);
+  return random_scene_from(main, albedo);
+}
+// scene 14: positions, material classes, metal parameters and second centres from StdRng::seed_from_u64(seed), as
+// scenes.rs:64-98 draws them (seed 5 there); the Lambertian albedos (thread_rng in the reference) as in scene 0
+SceneDef random_scene_stdrng(uint64_t seed) {
+  StdRng main(seed);
+  Stream albedo = scene_stream(seed, 1);
+  return random_scene_from(main, albedo);
 }
 
 static Texture earthmap(const SceneOpts& o) { return Texture::new_image_rgb8(o.texels, o.tex_w, o.tex_h); }
@@ -351,6 +363,7 @@ SceneDef scene_by_id(const SceneOpts& o) {
     case 11: return final_scene(o, true);
     case 12: return cornell_box_area();
     case 13: return area_light_plate();
+    case 14: return random_scene_stdrng(o.scene_seed);
     default: return small_scene();  // main.rs:123
   }
 }

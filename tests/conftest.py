@@ -30,6 +30,8 @@ SCENES = {
     # extensions: a Cube as an importance-sampled area light (RT_LIGHT_CUBE + RT_MAT_AREA_LIGHT)
     "cornell_box_area": (12, 1.0, 0, 50),
     "area_light_plate": (13, 1.0, 0, 5),
+    # random_scene with its geometry from StdRng::seed_from_u64(5) (parity unpinned: tests/test_stdrng.py)
+    "random_scene_stdrng": (14, 16.0 / 9.0, 0, 50),
 }
 
 

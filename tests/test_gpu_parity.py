@@ -78,7 +78,7 @@ def test_primary_hits_f32(name, w, earthmap):
 
 @pytest.mark.parametrize("name", ["random_scene", "two_spheres", "earth", "simple_light", "cube_scene",
                                   "small_scene", "cornell_box", "final_scene", "perlin_spheres", "final_scene_perlin",
-                                  "cornell_box_area", "area_light_plate"])
+                                  "cornell_box_area", "area_light_plate", "random_scene_stdrng"])
 def test_render_f64_follows_oracle_path_for_path(name, earthmap):
     hs, ds, os_, h, depth = _pair(name, earthmap)
     spp = 8
