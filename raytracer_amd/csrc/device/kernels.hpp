@@ -1855,6 +1855,16 @@ __global__ void tonemap_kernel(const float* __restrict__ accum, uint64_t n, floa
   }
 }
 
+// n dwords of zeros.  The render entries clear their accumulator and counter blocks with this, not with hipMemsetAsync:
+// captured into a HIP graph (rt_render_device_noalloc's callers), a memset node followed by a kernel node was replayed
+// without the kernel waiting for it (ROCm 7.2: units that finished early lost their sums from the second replay on);
+// kernel-after-kernel on one stream is ordered in a graph as it is on the stream.
+__global__ void zero_kernel(uint32_t* __restrict__ dst, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = 0u;
+}
+
 // dst[i] = ((dst[i] + src[i]) + src[n + i]) + ... over n_src images of n floats each, in that order (the accumulators
 // of the other devices' sample shards, rt_multi_render)
 __global__ void accum_add_kernel(float* __restrict__ dst, const float* __restrict__ src, uint64_t n, uint32_t n_src) {

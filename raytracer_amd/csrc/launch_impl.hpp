@@ -221,6 +221,14 @@ hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t
   RT_LAUNCH(tonemap_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, accum, n, inv_spp, out);
   return hipGetLastError();
 }
+hipError_t launch_zero(void* dst, size_t bytes, hipStream_t st) {  // bytes: a multiple of 4
+  const uint64_t n = bytes / 4;
+  if (n == 0) return hipSuccess;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  RT_LAUNCH(zero_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(dst), n);
+  return hipGetLastError();
+}
 hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, uint32_t n_src, hipStream_t st) {
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;

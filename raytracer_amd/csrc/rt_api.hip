@@ -1176,26 +1176,29 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
   }
   CameraView<R> cv = to_camera<R>(*cam);
   const SceneView<R>& sv = Side<R>::get(s).view;
-  HIP_TRY(hipMemsetAsync(blocks, 0, slots ? std::max<size_t>(n_launches, 1) * NOALLOC_SLOT_BYTES : sizeof(DeviceStats), stream));
-  HIP_TRY(hipEventRecord(s->ev0, stream));
+  static_assert(sizeof(DeviceStats) % 4 == 0 && NOALLOC_SLOT_BYTES % 4 == 0, "cleared in dwords");
+  HIP_TRY(launch_zero(blocks, slots ? std::max<size_t>(n_launches, 1) * NOALLOC_SLOT_BYTES : sizeof(DeviceStats), stream));
+  // (the two timing events only when somebody will read them: without stats the call is memsets and launches,
+  // nothing else — what a caller that captures it into a HIP graph wants to see on its stream)
+  if (stats) HIP_TRY(hipEventRecord(s->ev0, stream));
   uint32_t done = 0, launches = 0;
   bool first = true;
   const size_t accum_bytes = (size_t)p->width * p->height * 3 * sizeof(R);
-  if (p->spp == 0 && !accumulate) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
+  if (p->spp == 0 && !accumulate) HIP_TRY(launch_zero(d_accum, accum_bytes, stream));
   while (done < p->spp) {
     uint32_t n = std::min(per_launch, p->spp - done);
     LaunchShape sh = make_shape(s, p->width, p->height, n, sizeof(R) == 4 && !(p->flags & RT_FLAG_FORCE_BVH), cam, p->max_depth);
     int acc = (accumulate || !first) ? 1 : 0;
-    if ((sh.splits > 1 || sh.unit_samples > 0) && !acc) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
-    if (sh.unit_samples > 0 && !slots && !first) HIP_TRY(hipMemsetAsync(&s->dstats->unit_counter, 0, sizeof(unsigned int), stream));
+    if ((sh.splits > 1 || sh.unit_samples > 0) && !acc) HIP_TRY(launch_zero(d_accum, accum_bytes, stream));
+    if (sh.unit_samples > 0 && !slots && !first) HIP_TRY(launch_zero(&s->dstats->unit_counter, sizeof(unsigned int), stream));
     HIP_TRY(Side<R>::render(sv, cv, p->width, p->height, (uint32_t)(p->sample_offset + done), n, p->max_depth, p->seed,
                             acc, want_stats, d_accum, block(launches), sh, stream));
     done += n;
     first = false;
     ++launches;
   }
-  HIP_TRY(hipEventRecord(s->ev1, stream));
   if (stats) {
+    HIP_TRY(hipEventRecord(s->ev1, stream));
     DeviceStats hs;
     std::memset(&hs, 0, sizeof(hs));
     if (!slots) {
