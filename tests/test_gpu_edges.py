@@ -382,3 +382,36 @@ def test_units_kernel_on_ragged_images_and_odd_sample_counts(size, spp):
     acc = torch.full((h, w, 3), 2.0, dtype=torch.float32, device="cuda:0")
     ds.render_device(acc.data_ptr(), w, h, spp, 50, seed=4, sample_offset=2, accumulate=True)
     np.testing.assert_allclose(acc.cpu().numpy()[fin], (a + 2.0)[fin], rtol=3e-5, atol=1e-5)
+
+
+def test_two_scenes_on_two_streams_overlap_without_interference():
+    """include/rt.h: "use one rt_scene per stream".  Two scenes (a leaf-list one and a BVH-bound one), each with its own
+    stream, enqueued back to back without any host wait in between (stats == NULL keeps the calls asynchronous), several
+    rounds: each image equals the one the scene renders alone."""
+    import torch
+    import raytracer_amd as R
+    a = R.DeviceScene(R.HostScene(6, 1.0), 0)
+    b = R.DeviceScene(R.HostScene(0, 16 / 9), 0)
+    w = 160
+    ha, hb = R.image_height(w, 1.0), R.image_height(w, 16 / 9)
+    ref_a = torch.zeros((ha, w, 3), dtype=torch.float32, device="cuda:0")
+    ref_b = torch.zeros((hb, w, 3), dtype=torch.float32, device="cuda:0")
+    a.render_device(ref_a.data_ptr(), w, ha, 64, 50, seed=7, want_stats=False)
+    b.render_device(ref_b.data_ptr(), w, hb, 64, 50, seed=7, want_stats=False)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    out_a, out_b = torch.zeros_like(ref_a), torch.zeros_like(ref_b)
+    for _ in range(3):
+        out_a.fill_(-3.0)
+        out_b.fill_(-3.0)
+        torch.cuda.synchronize()
+        a.render_device(out_a.data_ptr(), w, ha, 64, 50, seed=7, want_stats=False, stream=sa.cuda_stream)
+        b.render_device(out_b.data_ptr(), w, hb, 64, 50, seed=7, want_stats=False, stream=sb.cuda_stream)
+        a.render_device(out_a.data_ptr(), w, ha, 64, 50, seed=7, sample_offset=64, accumulate=True, want_stats=False,
+                        stream=sa.cuda_stream)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out_b.cpu().numpy(), ref_b.cpu().numpy(), rtol=3e-5, atol=1e-5)
+        both = torch.zeros_like(ref_a)
+        a.render_device(both.data_ptr(), w, ha, 128, 50, seed=7, want_stats=False)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out_a.cpu().numpy(), both.cpu().numpy(), rtol=3e-5, atol=1e-4)
