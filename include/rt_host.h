@@ -22,7 +22,7 @@ typedef struct rth_scene_opts {
   int32_t scene_id;        /* main.rs:117-124: 0 random, 1 two_spheres, 2 earth, 3 simple_light, 4 cube_scene,
                               other small_scene; plus 6 cornell_box, 7 bvh_stress, 8 final_scene, 9 mixed_scene (parity-test
                               generator), and the extensions 10 perlin_spheres, 11 final_scene with the Perlin sphere,
-                              12 cornell_box_area (the ceiling light a box: RT_LIGHT_CUBE + RT_MAT_AREA_LIGHT), 13 area_light_plate;
+                              12 cornell_box_area (the ceiling light a box: RT_LIGHT_CUBE + RT_MAT_AREA_LIGHT), 13 area_light_plate, 15 area_light_list (the box light in a List of three lights);
                               14 random_scene with its geometry drawn from StdRng::seed_from_u64(scene_seed) like
                               scenes.rs:64-98 (parity unpinned, see rth_kat_stdrng) */
   int32_t rotate_bbox;     /* -1 scene default, 0 reference (Q3), 1 correct */

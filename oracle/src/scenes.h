@@ -266,6 +266,19 @@ inline void area_light_plate(SceneDef& s) {
   s.rotate_bbox = RotateBBox::Correct;
 }
 
+// 15: scene 13 with a second, spherical lamp and a dielectric bead in `lights` (a List of three: the box light, a
+// DiffuseLight sphere, a non-emitting sphere as scenes.rs:139-143 has one) — the box light inside List::pdf_value /
+// List::random (hittable.rs:492-497, 510-512).
+inline void area_light_list(SceneDef& s) {
+  area_light_plate(s);
+  Hittable lamp = Hittable::new_sphere(V3(-3.0, 2.0, 1.0), 0.5, Material::diffuse_light(V3(6.0, 6.0, 6.0)));
+  Hittable bead = Hittable::new_sphere(V3(2.5, 0.4, -1.0), 0.4, Material::dielectric(1.5));
+  s.world.push_back(lamp.clone());
+  s.world.push_back(bead.clone());
+  s.lights.push_back(std::move(lamp));
+  s.lights.push_back(std::move(bead));
+}
+
 // C4: ground + n random static spheres, material mix as random_scene; scene stream 0.
 inline void bvh_stress(SceneDef& s, uint64_t seed, uint32_t n) {
   Texture checker = Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9));
@@ -475,6 +488,7 @@ inline SceneDef build_scene_def(const SceneSpec& spec) {
     case 12: cornell_box_area(s); break;
     case 13: area_light_plate(s); break;
     case 14: random_scene_stdrng(s, spec.scene_seed); break;
+    case 15: area_light_list(s); break;
     default: small_scene(s); break;
   }
   return s;

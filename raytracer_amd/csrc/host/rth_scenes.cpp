@@ -170,6 +170,17 @@ SceneDef area_light_plate() {  // 13: a grey floor under a box light, black sky:
   return s;
 }
 
+SceneDef area_light_list() {  // 15: the box light of scene 13 in a List with a sphere lamp and a non-emitting bead
+  SceneDef s = area_light_plate();
+  const Hittable lamp = Hittable::new_sphere(Point(-3.0, 2.0, 1.0), 0.5, Material::new_diffuse_light(Color(6.0, 6.0, 6.0)));
+  const Hittable bead = Hittable::new_sphere(Point(2.5, 0.4, -1.0), 0.4, Material::new_dielectric(1.5));
+  s.world.push_back(lamp);
+  s.world.push_back(bead);
+  s.lights.push_back(lamp);
+  s.lights.push_back(bead);
+  return s;
+}
+
 SceneDef bvh_stress(uint64_t seed, uint32_t n) {
   SceneDef s = with_reference_view();
   s.world.reserve((size_t)n + 1);
@@ -364,6 +375,7 @@ SceneDef scene_by_id(const SceneOpts& o) {
     case 12: return cornell_box_area();
     case 13: return area_light_plate();
     case 14: return random_scene_stdrng(o.scene_seed);
+    case 15: return area_light_list();
     default: return small_scene();  // main.rs:123
   }
 }

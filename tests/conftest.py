@@ -32,6 +32,7 @@ SCENES = {
     "area_light_plate": (13, 1.0, 0, 5),
     # random_scene with its geometry from StdRng::seed_from_u64(5) (parity unpinned: tests/test_stdrng.py)
     "random_scene_stdrng": (14, 16.0 / 9.0, 0, 50),
+    "area_light_list": (15, 1.0, 0, 8),  # the box light inside a lights List (with a sphere lamp and a non-emitting bead)
 }
 
 

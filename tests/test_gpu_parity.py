@@ -78,7 +78,7 @@ def test_primary_hits_f32(name, w, earthmap):
 
 @pytest.mark.parametrize("name", ["random_scene", "two_spheres", "earth", "simple_light", "cube_scene",
                                   "small_scene", "cornell_box", "final_scene", "perlin_spheres", "final_scene_perlin",
-                                  "cornell_box_area", "area_light_plate", "random_scene_stdrng"])
+                                  "cornell_box_area", "area_light_plate", "random_scene_stdrng", "area_light_list"])
 def test_render_f64_follows_oracle_path_for_path(name, earthmap):
     hs, ds, os_, h, depth = _pair(name, earthmap)
     spp = 8
@@ -115,7 +115,7 @@ def _chunk_means(render_chunk, spp, chunks, clip):
 
 
 @pytest.mark.parametrize("name", ["random_scene", "simple_light", "cornell_box", "earth", "small_scene", "final_scene",
-                                  "bvh_stress", "perlin_spheres", "cornell_box_area", "area_light_plate"])
+                                  "bvh_stress", "perlin_spheres", "cornell_box_area", "area_light_plate", "area_light_list"])
 def test_render_f32_within_monte_carlo_noise(name, earthmap):
     """f32 production kernel vs oracle, different seeds, matched spp (main.rs:160-167's estimator): the
     difference of two independent estimates must look like noise of the MEASURED per-pixel variance —
