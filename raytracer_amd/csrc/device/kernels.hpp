@@ -527,7 +527,7 @@ struct RenderArgs {
   uint32_t wave_tiles_x, wave_tiles, total_units;
   uint32_t leaf_shift;  // refill kernel: run the leaf tests once (walking lanes >> leaf_shift) lanes wait at a leaf
   uint32_t direct_accum;  // units kernel: no LDS accumulators, finished samples go to the image by float atomics
-  uint32_t xcd_chunk;   // refill kernel: block_slot's mode
+  uint32_t xcd_chunk;   // render_kernel, refill kernel: block_slot's mode
   uint32_t tile_band;   // refill kernel: band_order's band height in tiles
   uint64_t seed;
 };
@@ -558,8 +558,9 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : (size
     __syncthreads();
   }
   const Light<R>* lights = sc.n_lights <= LDS_MAX_LIGHTS ? s_lights : sc.lights;
-  uint32_t px, py;
-  tile_pixel(a.width, px, py);
+  uint32_t px, py, my_tile, my_split;
+  block_slot(a.xcd_chunk, my_tile, my_split);  // (tile, split) slots dealt to the XCDs split-wise: see block_slot
+  tile_pixel(a.width, px, py, my_tile);
   const bool active = px < a.width && py < a.height;
   const uint32_t pixel = py * a.width + px;
 
@@ -570,9 +571,9 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : (size
 
   if (active) {
     const Vec3<R> background(sc.background[0], sc.background[1], sc.background[2]);
-    // this block row's slice of the launch's samples
-    uint32_t s = (uint32_t)(((uint64_t)a.n_samples * blockIdx.y) / a.splits);
-    const uint32_t s_end = (uint32_t)(((uint64_t)a.n_samples * (blockIdx.y + 1)) / a.splits);
+    // this workgroup's slice of the launch's samples
+    uint32_t s = (uint32_t)(((uint64_t)a.n_samples * my_split) / a.splits);
+    const uint32_t s_end = (uint32_t)(((uint64_t)a.n_samples * (my_split + 1)) / a.splits);
     bool alive = false;
     RayT<R> ray;
     Vec3<R> thr, L;

@@ -923,7 +923,8 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   uint32_t splits = waves >= target ? 1 : (target + waves - 1) / waves;
   if (sh.trav == 2) splits = std::min(splits, std::max(1u, n_samples / 6u));
   static const char* fs = getenv("RT_SPLITS");  // tuning override
-  if (sh.trav == 2 && sh.xcd_chunk == 1 && splits >= 5) {
+  static const bool grid_all = getenv("RT_XCD_ALL_OFF") == nullptr;  // A/B: the same for the reference-order kernels
+  if ((sh.trav == 2 || (grid_all && sh.trav == 0)) && sh.xcd_chunk == 1 && splits >= 5) {
     // a multiple of 8, so that block_slot can give every XCD whole splits (mode 1)
     const uint32_t up = (splits + 7u) / 8u * 8u;
     splits = up <= std::max(1u, n_samples / 4u) ? up : splits / 8u * 8u;
