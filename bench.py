@@ -307,6 +307,9 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # set the communicator up now (RCCL does it at the first collective), so that a run with --warmup 0
+            # does not time it
+            dist.all_reduce(torch.zeros(1, device=torch.device("cuda", local_rank)))
 
     wl = Workload(R, torch, args.scene, args.width, args.aspect, args.n, local_rank)
     width, height = wl.width, wl.height
