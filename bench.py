@@ -301,7 +301,10 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under a launcher (WORLD_SIZE set) the process group is set up even for one rank, so that
+    # `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` runs the RCCL path on a one-GPU box
+    distributed = world > 1 or "WORLD_SIZE" in os.environ
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -321,7 +324,7 @@ def main():
         offset = (i * world + rank) * args.spp
         st = wl.ds.render_device(wl.accum.data_ptr(), width, height, args.spp, args.max_depth, seed=1,
                                  sample_offset=offset, spp_per_launch=args.spp_per_launch, stream=wl.stream)
-        if rehearsal and world > 1:  # gloo reduces host tensors
+        if rehearsal and distributed:  # gloo reduces host tensors
             host = wl.accum.cpu()
             allreduce_accum(host)
             wl.accum.copy_(host)
@@ -332,7 +335,7 @@ def main():
         return st
 
     def sync():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -354,7 +357,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     tot = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device="cpu" if rehearsal else dev)
-    if world > 1:
+    if distributed:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -404,7 +407,7 @@ def main():
             out["other_configs"] = other_configs(R, torch, local_rank)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
     return 0

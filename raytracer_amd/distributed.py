@@ -23,8 +23,9 @@ def shard_samples(total_spp, rank, world_size, base_offset=0):
 
 
 def allreduce_accum(accum):
-    """Sum the per-rank accumulators in place (RCCL on GPUs, gloo on CPU).  No-op without a group."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """Sum the per-rank accumulators in place (RCCL on GPUs, gloo on CPU).  No-op without a group (a group of one
+    rank does go through the collective: that is how the RCCL path is rehearsed on a one-GPU box)."""
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(accum, op=dist.ReduceOp.SUM)
     return accum
 
