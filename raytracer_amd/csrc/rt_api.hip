@@ -919,16 +919,27 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   // their size, and what is left to balance is the uneven cost of image regions ACROSS waves: many short waves
   // (measured on final_scene 1024^2 x 512 spp: 24 k waves 6.4, 98 k 8.0, 197 k 8.3, 393 k 8.1, 1.5 M 6.3 Grays/s), but
   // no fewer than 6 samples per wave and split (random_scene 400 x 225 x 100 spp: 16 splits 7.0, 64 splits 6.0 Grays/s)
-  const uint32_t target = tw ? (uint32_t)std::max(1, atoi(tw)) : (sh.trav == 2 ? 2u * TARGET_WAVES : TARGET_WAVES);
+  // The reference-order kernel (lane = pixel; what scenes with non-conservative boxes, RT_FLAG_FORCE_BVH and the f64 audit
+  // run on) wants FEWER, longer workgroups: about four rounds of the chip's wave slots, one split once the image alone
+  // has that many waves, and otherwise a multiple of 8 (below), so that its workgroups are dealt to the XCDs (measured,
+  // ms: simple_light 400 x 267 x 100 spp: 8 splits 1.29, 16: 1.39, 32: 1.61, 64: 1.90; Cornell forced onto it, 256^2 x
+  // 256 spp: 8: 2.71, 16: 2.40, 32: 2.42, 64: 2.70; 1920 x 1080 x 64 spp: 1: 8.7, 2: 8.6, 8: 9.5, 16: 11.3; 3840 x 2160 x
+  // 64 spp: 1: 30.4, 8: 36.9; the reference's default job 1200 x 800 x 500 spp: 1: 40.4, 2: 37.0, 4: 35.6, 8: 35.8,
+  // 16: 37.2; f64 Cornell 1024^2 x 64 spp: 1: 216, 4: 199, 8: 182, 16: 184)
+  const uint32_t target = tw ? (uint32_t)std::max(1, atoi(tw)) : (sh.trav == 2 ? 2u * TARGET_WAVES : sh.trav == 0 ? 24u * 1024u : TARGET_WAVES);
   uint32_t splits = waves >= target ? 1 : (target + waves - 1) / waves;
   if (sh.trav == 2) splits = std::min(splits, std::max(1u, n_samples / 6u));
   static const char* fs = getenv("RT_SPLITS");  // tuning override
   static const bool grid_all = getenv("RT_XCD_ALL_OFF") == nullptr;  // A/B: the same for the reference-order kernels
-  if ((sh.trav == 2 || (grid_all && sh.trav == 0)) && sh.xcd_chunk == 1 && splits >= 5) {
+  if (((sh.trav == 2 && splits >= 5) || (grid_all && sh.trav == 0 && splits >= 2)) && sh.xcd_chunk == 1) {
     // a multiple of 8, so that block_slot can give every XCD whole splits (mode 1)
     const uint32_t up = (splits + 7u) / 8u * 8u;
-    splits = up <= std::max(1u, n_samples / 4u) ? up : splits / 8u * 8u;
-    if (splits == 0) splits = std::min(8u, n_samples);
+    if (up <= std::max(1u, n_samples / (sh.trav == 0 ? 2u : 4u))) {
+      splits = up;
+    } else if (sh.trav == 2) {
+      splits = splits / 8u * 8u;
+      if (splits == 0) splits = std::min(8u, n_samples);
+    }  // (reference-order kernel with few samples: as computed, workgroups in grid order)
   }
   if (fs) splits = (uint32_t)std::max(1, atoi(fs));
   sh.splits = std::max(1u, std::min(splits, n_samples));

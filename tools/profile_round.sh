@@ -17,5 +17,5 @@ bash tools/pmc_walk.sh ${tag}_c1 0 0 400 100 > $out/walk_c1.txt 2>&1 &&
 bash tools/pmc_walk.sh ${tag}_c3 8 0 1024 512 1.0 > $out/walk_c3.txt 2>&1 &&
 bash tools/pmc_walk.sh ${tag}_c4 7 1000000 3840 4 > $out/walk_c4.txt 2>&1
 rc=$?
-tail -8 $out/walk_c*.txt
+for f in $out/walk_c*.txt; do tail -n 8 $f; done
 exit $rc
