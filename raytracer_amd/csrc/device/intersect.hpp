@@ -373,6 +373,9 @@ RT_DEV bool leaf_t_unified(const SceneView<float>& sc, uint32_t ref, const RayT<
   return true;
 }
 
+#ifndef RT_TRAVERSE_PHASED
+#define RT_TRAVERSE_PHASED 1
+#endif
 // world.hit(r, t_min, +inf) — hittable.rs:400-412 as an iterative DFS.  `stack` is this
 // lane's column of the LDS stack: entry i lives at stack[i * stride].
 template <typename R, bool STATS>
@@ -385,6 +388,45 @@ RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng
   const Vec3<R> inv_d = inverse3(r.d);
   const R a = sqrlen(r.d);
   uint32_t sp = 0;
+#if RT_TRAVERSE_PHASED
+  // Same per-lane visiting order, run in two wave phases: every lane first descends through inner nodes until it
+  // stands at a leaf (or has nothing left), then the lanes at a leaf run their leaf tests TOGETHER — instead of
+  // one lane's box test and another's (much longer) leaf test taking turns in every iteration.
+  bool walking = true;
+  for (;;) {
+    while (walking && !(cur & REF_LEAF)) {
+      cnt.template inc<ST_NODES>();
+      Node<R> n = sc.nodes[cur];
+      R lo = t_min, hi = closest;
+      if (slab_hit(n.lo, n.hi, r.o, inv_d, lo, hi)) {
+        stack[sp * stride] = n.right;
+        ++sp;
+        cur = n.left;
+      } else if (sp == 0) {
+        walking = false;
+      } else {
+        --sp;
+        cur = stack[sp * stride];
+      }
+    }
+    if (!walking) break;
+    R t;
+    bool h;
+    if constexpr (sizeof(R) == 4)
+      h = leaf_t_unified(sc, cur, r, inv_d, a, t_min, closest, rng, t, cnt);
+    else if (ref_kind(cur) == LEAF_COMPLEX)
+      h = complex_t(sc, ref_index(cur), r, t_min, closest, rng, t, cnt);
+    else
+      h = prim_t(sc, cur, r, inv_d, a, t_min, closest, t, cnt);
+    if (h && t < closest) {
+      closest = t;
+      best = cur;
+    }
+    if (sp == 0) break;
+    --sp;
+    cur = stack[sp * stride];
+  }
+#else
   for (;;) {
     if (!(cur & REF_LEAF)) {
       cnt.template inc<ST_NODES>();
@@ -414,6 +456,7 @@ RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng
     --sp;
     cur = stack[sp * stride];
   }
+#endif
 }
 
 // ORDERED walk (f32 production path for scenes too large for the leaf list).
