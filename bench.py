@@ -212,7 +212,7 @@ def f64_leg(wl, args):
     avg_ms = kernel_ms / max(1, launches)
     tflops = flops_per_ray * (rays / max(1, launches)) / (avg_ms * 1e-3) / 1e12
     return {
-        "dtype": "f64", "entry": "rt_render_f64_device", "kernel": "render_kernel<double, ..., TRAV_REFERENCE>",
+        "dtype": "f64", "entry": "rt_render_f64_device", "kernel": "render_persist_kernel<double, ..., TRAV_REFERENCE>",
         "workload": f"{args.scene} {wl.width}x{wl.height}, {spp} spp, max depth {args.max_depth}",
         "steps": args.f64_steps, "warmup": 1, "ms_per_step": 1e3 * secs / args.f64_steps,
         "value": rays / secs / 1e6, "unit": "Mrays/s", "msamples_per_s": samples / secs / 1e6,

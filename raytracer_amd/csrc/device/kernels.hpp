@@ -1210,13 +1210,17 @@ constexpr uint32_t UNIT_RING = 32;
 #ifndef RT_PERSIST_MIN_WAVES
 #define RT_PERSIST_MIN_WAVES 6  // measured (after sphere_roots stopped the f64 hoist): 4: 54.2, 5: 61.1, 6 (80 VGPRs, 32 B scratch): 65.3, 7: 63.1 Grays/s
 #endif
-template <bool STATS>
-__global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_kernel(SceneView<float> sc, CameraView<float> cam,
-                                                                                  RenderArgs a, float* __restrict__ accum,
-                                                                                  DeviceStats* stats) {
-  using R = float;
+// TRAV_REFERENCE (any precision): the same hand-out around the reference-order BVH walk — what scenes with
+// non-conservative boxes, RT_FLAG_FORCE_BVH and the f64 audit run on; EARLY_EXIT / NOISE as in render_kernel.
+template <typename R, bool STATS, int TRAV = TRAV_LINEAR, bool EARLY_EXIT = true, bool NOISE = false>
+__global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WAVES : (sizeof(R) == 8 ? RT_RENDER_F64_MIN_WAVES : RT_RENDER_MIN_WAVES))
+    render_persist_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a, R* __restrict__ accum, DeviceStats* stats) {
+  constexpr bool LINEAR = TRAV == TRAV_LINEAR;
+  static_assert(TRAV == TRAV_LINEAR || TRAV == TRAV_REFERENCE, "leaf list or reference-order walk");
+  extern __shared__ uint32_t lds_stack[];  // TRAV_REFERENCE: the walk's stack
+  [[maybe_unused]] uint32_t* stack = lds_stack + threadIdx.x;
   __shared__ Light<R> s_lights[LDS_MAX_LIGHTS];
-  __shared__ float s_lin[LIN_MAX_LEAVES * LIN_DWORDS];
+  __shared__ float s_lin[LINEAR ? LIN_MAX_LEAVES * LIN_DWORDS : 1];
   __shared__ volatile uint32_t s_unit_xy[BLOCK / 64][UNIT_RING];  // tile origin x | y << 16
   __shared__ volatile uint32_t s_unit_k[BLOCK / 64][UNIT_RING];   // which sample range of the launch
   __shared__ uint32_t s_red[BLOCK / 64][2];                       // wave-wide max / min scratch
@@ -1225,7 +1229,8 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
     constexpr uint32_t LW = sizeof(Light<R>) / 4;
     for (uint32_t i = threadIdx.x; i < n_l * LW; i += BLOCK)
       reinterpret_cast<uint32_t*>(s_lights)[i] = reinterpret_cast<const uint32_t*>(sc.lights)[i];
-    for (uint32_t i = threadIdx.x; i < sc.n_linear * LIN_DWORDS; i += BLOCK) s_lin[i] = __uint_as_float(sc.linear_rec[i]);
+    if constexpr (LINEAR)
+      for (uint32_t i = threadIdx.x; i < sc.n_linear * LIN_DWORDS; i += BLOCK) s_lin[i] = __uint_as_float(sc.linear_rec[i]);
     __syncthreads();
   }
   const Light<R>* lights = sc.n_lights <= LDS_MAX_LIGHTS ? s_lights : sc.lights;
@@ -1233,8 +1238,11 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
   const Vec3<R> background(sc.background[0], sc.background[1], sc.background[2]);
   // wave-uniform reciprocals of main.rs:161-163, pinned to scalar registers (the compiler keeps the result
   // of a VALU rcp in a vector register otherwise, and at 96 VGPRs that register is spilled to scratch)
-  const R inv_wm1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rrcp((R)(a.width - 1)))));
-  const R inv_hm1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rrcp((R)(a.height - 1)))));
+  [[maybe_unused]] float inv_wm1 = 0.0f, inv_hm1 = 0.0f;
+  if constexpr (LINEAR) {
+    inv_wm1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rrcp((float)(a.width - 1)))));
+    inv_hm1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rrcp((float)(a.height - 1)))));
+  }
 
   Cnt<STATS> cnt;
   cnt.clear();
@@ -1260,7 +1268,7 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
     const bool needy = !alive && s == s_end && !lane_done;
     if (__ballot(needy)) {  // wave-uniform
       if (needy && have_pixel) {
-        float* out = accum + 3ull * (py * a.width + px);
+        R* out = accum + 3ull * (py * a.width + px);
         atomicAdd(out + 0, acc.x);
         atomicAdd(out + 1, acc.y);
         atomicAdd(out + 2, acc.z);
@@ -1323,8 +1331,14 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
       rng.begin(0);
       R ju = rng.next<R>();
       R jv = rng.next<R>();
-      R u = ((R)px + ju) * inv_wm1;                  // main.rs:161
-      R v = ((R)(a.height - py - 1) + jv) * inv_hm1;  // main.rs:162-163
+      R u, v;
+      if constexpr (LINEAR) {
+        u = ((R)px + ju) * inv_wm1;                  // main.rs:161
+        v = ((R)(a.height - py - 1) + jv) * inv_hm1;  // main.rs:162-163
+      } else {  // (as render_kernel: the quotient itself, which is what the oracle computes)
+        u = rdiv((R)px + ju, (R)(a.width - 1));
+        v = rdiv((R)(a.height - py - 1) + jv, (R)(a.height - 1));
+      }
       ray = camera_ray(cam, u, v, rng);
       thr = Vec3<R>(1, 1, 1);
       L = Vec3<R>(0, 0, 0);
@@ -1336,10 +1350,14 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
     RT_STAMP(3);  // bounce Philox block
     R t;
     uint32_t best;
-    if (sc.linear_has_media)  // wave-uniform
-      traverse_linear<STATS, true>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
-    else
-      traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
+    if constexpr (LINEAR) {
+      if (sc.linear_has_media)  // wave-uniform
+        traverse_linear<STATS, true>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
+      else
+        traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
+    } else {
+      traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+    }
     RT_STAMP(4);  // leaf-list walk
     bool cont;
     if (best == REF_NONE) {  // main.rs:104
@@ -1350,20 +1368,25 @@ __global__ void __launch_bounds__(BLOCK, RT_PERSIST_MIN_WAVES) render_persist_ke
       cnt.template inc<ST_CLOSEST>();
       HitRec<R> h;
       Material<R> mat;
-      lin_hit_record(sc, s_lin + best * LIN_DWORDS, ray, t, h, mat);
+      if constexpr (LINEAR) {
+        lin_hit_record(sc, s_lin + best * LIN_DWORDS, ray, t, h, mat);
+      } else {
+        make_hit_record(sc, best, ray, t, false, h);
+        mat = sc.materials[h.material];
+      }
       RT_STAMP(5);  // hit record
-      cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
+      cont = shade<R, STATS, NOISE>(sc, lights, mat, h, ray, thr, L, rng, cnt);
     }
     RT_STAMP(6);  // shade (or miss)
     if (rng.slot == a.max_depth && cont) {  // the next ray_color call would return 0
       depth_exhausted(L, thr);
       cont = false;
     }
-    if (cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
+    if (EARLY_EXIT && cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
     if (!cont) {
       const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
       if (!fin) ++nonfinite;
-      if (fin) acc = acc + L;
+      if (fin || sizeof(R) == 8) acc = acc + L;  // (the f64 audit kernel lets it poison the pixel like the reference does)
       alive = false;
       ++s;
     }

@@ -49,9 +49,9 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
 #if RT_HAS_LINEAR
   if (shape.trav == TRAV_LINEAR && shape.unit_samples > 0) {  // persistent form: grid = workers, not tiles
     if (stats)
-      RT_LAUNCH((render_persist_kernel<true>), grid, block, 0, st, sc, cam, a, accum, dstats);
+      RT_LAUNCH((render_persist_kernel<RT_REAL, true>), grid, block, 0, st, sc, cam, a, accum, dstats);
     else
-      RT_LAUNCH((render_persist_kernel<false>), grid, block, 0, st, sc, cam, a, accum, dstats);
+      RT_LAUNCH((render_persist_kernel<RT_REAL, false>), grid, block, 0, st, sc, cam, a, accum, dstats);
     return hipGetLastError();
   }
   if (shape.trav == TRAV_LINEAR) {
@@ -103,6 +103,17 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   // audit build, and as a separate instantiation in f32, launched only for scenes that have a noise texture
   // (rt_api.hip routes those here) so that no other kernel pays registers for it.
   constexpr bool F64 = sizeof(RT_REAL) == 8;
+  if constexpr (F64) {
+    if (shape.trav == TRAV_REFERENCE && shape.unit_samples > 0) {  // persistent form of the audit kernel (rt_api.hip: make_shape)
+      if (stats)
+        RT_LAUNCH((render_persist_kernel<RT_REAL, true, TRAV_REFERENCE, RT_EARLY_EXIT, true>), grid, block, lds, st, sc, cam, a,
+                  accum, dstats);
+      else
+        RT_LAUNCH((render_persist_kernel<RT_REAL, false, TRAV_REFERENCE, RT_EARLY_EXIT, true>), grid, block, lds, st, sc, cam, a,
+                  accum, dstats);
+      return hipGetLastError();
+    }
+  }
   if (F64 || sc.has_noise) {
     if (stats)
       RT_LAUNCH((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE, true>), grid, block, lds, st, sc,

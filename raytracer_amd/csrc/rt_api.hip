@@ -891,7 +891,7 @@ int check_camera(const rt_camera* cam) {
 }
 
 LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_samples, bool f32_fast = false,
-                       const rt_camera* cam = nullptr, uint32_t max_depth = 0) {
+                       const rt_camera* cam = nullptr, uint32_t max_depth = 0, bool f64 = false) {
   LaunchShape sh;
   sh.trav = 0;  // the reference's left-first walk: always valid
   // (a scene with a Perlin texture, an extension, renders on the reference-order kernel: see launch_impl.hpp)
@@ -958,6 +958,26 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
     if (units <= 0xFFF00000ull && n_samples > 0) {  // (every wave overshoots the counter once: keep clear of 2^32)
       sh.total_units = (uint32_t)units;
       sh.tiles = (uint32_t)std::min<uint64_t>((units + 3) / 4, 256u * 8u);  // workgroups: at most 8 per CU can be resident
+      sh.splits = 1;
+    } else {
+      sh.unit_samples = 0;
+    }
+  }
+  // The f64 audit kernel (reference-order walk, paths of 1..50 rays walked to their end): the same persistent form
+  // (render_persist_kernel<double, ..., TRAV_REFERENCE>) — Cornell 1024^2 x 64 spp 82.7 -> 52.1 ms, x 256 spp 223.7 ->
+  // 165 ms (units of 2 / 4 / 8 / 16 / 32 / 64 samples: 169 / 165 / 166 / 167 / 179 / 193 ms).  RT_REF_GRID keeps one
+  // workgroup per (tile, split) (A/B).  Not for the f32 reference-order kernel: its jobs are short-path scenes
+  // (the reference's default job, depth 5: 35.9 ms as a grid, 38.2 ms at best in this form).
+  static const bool ref_grid = getenv("RT_REF_GRID") != nullptr;
+  if (sh.trav == 0 && f64 && !ref_grid && max_depth > 0 && n_samples > 0) {
+    const uint32_t auto_unit = std::min(8u, std::max(2u, n_samples / 16));
+    sh.unit_samples = std::max(1u, std::min(us ? (uint32_t)std::max(1, atoi(us)) : auto_unit, n_samples));
+    sh.wave_tiles_x = (w + 7) / 8;
+    sh.wave_tiles = sh.wave_tiles_x * ((h + 7) / 8);
+    const uint64_t units = (uint64_t)sh.wave_tiles * ((n_samples + sh.unit_samples - 1) / sh.unit_samples);
+    if (units <= 0xFFF00000ull) {
+      sh.total_units = (uint32_t)units;
+      sh.tiles = (uint32_t)std::min<uint64_t>((units + 3) / 4, 256u * 8u);
       sh.splits = 1;
     } else {
       sh.unit_samples = 0;
@@ -1199,7 +1219,8 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
   if (p->spp == 0 && !accumulate) HIP_TRY(launch_zero(d_accum, accum_bytes, stream));
   while (done < p->spp) {
     uint32_t n = std::min(per_launch, p->spp - done);
-    LaunchShape sh = make_shape(s, p->width, p->height, n, sizeof(R) == 4 && !(p->flags & RT_FLAG_FORCE_BVH), cam, p->max_depth);
+    LaunchShape sh = make_shape(s, p->width, p->height, n, sizeof(R) == 4 && !(p->flags & RT_FLAG_FORCE_BVH), cam, p->max_depth,
+                                sizeof(R) == 8);
     int acc = (accumulate || !first) ? 1 : 0;
     if ((sh.splits > 1 || sh.unit_samples > 0) && !acc) HIP_TRY(launch_zero(d_accum, accum_bytes, stream));
     if (sh.unit_samples > 0 && !slots && !first) HIP_TRY(launch_zero(&s->dstats->unit_counter, sizeof(unsigned int), stream));
