@@ -384,6 +384,29 @@ def test_units_kernel_on_ragged_images_and_odd_sample_counts(size, spp):
     np.testing.assert_allclose(acc.cpu().numpy()[fin], (a + 2.0)[fin], rtol=3e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("size", [(2, 2), (37, 23), (130, 3)])
+def test_f64_persistent_kernel_on_ragged_images_accumulates_on_the_device(size):
+    """The f64 audit kernel runs in the persistent form (units of an 8x8 tile x a few samples, f64 atomics): images that
+    fill no tile, sample counts that are no multiple of the unit size, and adding onto an existing device accumulator
+    must give the oracle's sums."""
+    import torch
+    import oracle_ffi as O
+    import raytracer_amd as R
+    w, h = size
+    hs = R.HostScene(6, w / h)
+    ds = R.DeviceScene(hs, 0)
+    o, ocnt, _ = O.OracleScene(6, w / h).render(w, h, 11, 50, seed=4, sample_offset=2)
+    acc = torch.full((h, w, 3), 2.0, dtype=torch.float64, device="cuda:0")
+    s1 = ds.render_device(acc.data_ptr(), w, h, 7, 50, seed=4, sample_offset=2, accumulate=True, f64=True, stats=True)
+    s2 = ds.render_device(acc.data_ptr(), w, h, 4, 50, seed=4, sample_offset=9, accumulate=True, f64=True, stats=True)
+    torch.cuda.synchronize()
+    assert s1["rays"] + s2["rays"] == ocnt["rays"]
+    got = acc.cpu().numpy() - 2.0
+    fin = np.isfinite(o)
+    assert (np.isfinite(got) == fin).all()
+    np.testing.assert_allclose(got[fin], o[fin], rtol=1e-9, atol=1e-9)
+
+
 def test_two_scenes_on_two_streams_overlap_without_interference():
     """include/rt.h: "use one rt_scene per stream".  Two scenes (a leaf-list one and a BVH-bound one), each with its own
     stream, enqueued back to back without any host wait in between (stats == NULL keeps the calls asynchronous), several
