@@ -58,10 +58,11 @@ if traffic:
     L.append("")
 
 walks = [("c1", "C1 random_scene 400x225 x 100 spp"), ("c3", "C3 final_scene 1024^2 x 512 spp"),
-         ("c4", "C4 bvh_stress 10^6 spheres 3840x2160 x 4 spp")]
+         ("c4", "C4 bvh_stress 10^6 spheres 3840x2160 x 4 spp"),
+         ("f64", "f64 audit kernel, Cornell 1024^2 x 256 spp")]
 have = [(k, t) for k, t in walks if os.path.exists(os.path.join(src, f"walk_{k}.txt"))]
 if have:
-    L += ["## SQ / TCC / TCP passes of the BVH-bound configs (`tools/pmc_walk.sh`, one fast-path render each, five `--pmc` runs)", ""]
+    L += ["## SQ / TCC / TCP passes of the BVH-bound configs and of the f64 audit kernel (`tools/pmc_walk.sh`, one render each, five `--pmc` runs)", ""]
     for k, title in have:
         body = []
         for line in open(os.path.join(src, f"walk_{k}.txt")):
@@ -70,7 +71,8 @@ if have:
                 body.append(line)
             elif "kernel_ms" in line and not any("kernel_ms" in b for b in body):
                 body.append(line.split(":", 1)[-1])
-        L += [f"### {title} — `render_units_kernel`", "", "```"] + body + ["```", ""]
+        kern = "render_persist_kernel<double, ..., TRAV_REFERENCE>" if k == "f64" else "render_units_kernel"
+        L += [f"### {title} — `{kern}`", "", "```"] + body + ["```", ""]
 
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
 print("\n".join(L[:40]))
