@@ -250,7 +250,11 @@ RT_DEV bool shade(const SceneView<R>& sc, const Light<R>* lights, const Material
   // (NOISE = the extension instantiation: Perlin textures, RT_MAT_AREA_LIGHT, RT_LIGHT_CUBE)
   if (m.tag == MAT_DIFFUSE_LIGHT || (NOISE && m.tag == MAT_AREA_LIGHT)) {  // scatter -> None: return emitted (main.rs:101)
     cnt.template inc<ST_EMITTER>();
-    if (h.front_face || (NOISE && m.tag == MAT_AREA_LIGHT)) L = madd(L, thr, material_color<R, NOISE>(sc, m, h));
+    if (h.front_face || (NOISE && m.tag == MAT_AREA_LIGHT))
+      L = madd(L, thr, material_color<R, NOISE>(sc, m, h));
+    else  // material.rs:118-126: the back face emits Color::new(), and the callers still multiply that zero into their
+          // attenuation * scattering_pdf / pdf_value (main.rs:93-97): NaN where a vertex up the path had pdf_value 0 (Q9)
+      L = madd(L, thr, Vec3<R>(0, 0, 0));
     return false;
   }
   if (m.tag == MAT_DIELECTRIC) {  // material.rs:66-87; emitted is dropped (main.rs:81-83)

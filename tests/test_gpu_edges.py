@@ -407,6 +407,26 @@ def test_f64_persistent_kernel_on_ragged_images_accumulates_on_the_device(size):
     np.testing.assert_allclose(got[fin], o[fin], rtol=1e-9, atol=1e-9)
 
 
+def test_back_face_of_an_emitter_still_multiplies_its_zero_up_the_path():
+    """material.rs:118-126 + main.rs:93-97: a light hit from behind emits Color::new(), and every caller up the
+    recursion still multiplies that zero into attenuation * scattering_pdf / pdf_value — NaN where a vertex had
+    pdf_value 0 (Q9).  Found by tests/sweep_mixed.py (generated scene, seed 1181, 150 objects: sample 2 of pixel
+    (48, 38) ends on the back of a light behind such a vertex): the f64 kernel's NaN pixels are the oracle's."""
+    import oracle_ffi as O
+    import raytracer_amd as R
+    w, asp, seed = 64, 1.5, 1181
+    h = R.image_height(w, asp)
+    hs = R.HostScene(9, asp, n=150, scene_seed=seed)
+    ds = R.DeviceScene(hs, 0)
+    g, _ = ds.render(w, h, 4, 10, seed=seed, f64=True)
+    o, _, _ = O.OracleScene(9, asp, n=150, scene_seed=seed).render(w, h, 4, 10, seed=seed)
+    assert np.isnan(o[38, 48]).all() and np.isnan(g[38, 48]).all()
+    assert (np.isfinite(o) == np.isfinite(g)).all()
+    # f32: a non-finite sample is dropped (or the path has stopped at zero throughput before): the image stays finite
+    f, sf = ds.render(w, h, 4, 10, seed=seed, stats=True)
+    assert np.isfinite(f).all()
+
+
 def test_two_scenes_on_two_streams_overlap_without_interference():
     """include/rt.h: "use one rt_scene per stream".  Two scenes (a leaf-list one and a BVH-bound one), each with its own
     stream, enqueued back to back without any host wait in between (stats == NULL keeps the calls asynchronous), several
