@@ -251,7 +251,10 @@ int rt_primary_hits_fast(rt_scene* scene, const rt_camera* cam, uint32_t width, 
 int rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
               float* accum_rgb, rt_stats* stats);
 /* Audit build of the same kernel in f64 with contraction off: draw-for-draw and
- * branch-for-branch comparable with the CPU oracle.  Not a production path.             */
+ * branch-for-branch comparable with the CPU oracle.  Not a production path.
+ * Every SAMPLE is the oracle's to the last bit (up to libm's sin / cos); a pixel's samples are summed in
+ * units that reach the image by f64 atomic adds, so the last bits of a pixel SUM depend on the order in
+ * which its units finish (1e-16 relative; the same holds for the f32 entries at 1e-7).             */
 int rt_render_f64(rt_scene* scene, const rt_camera* cam, const rt_params* params,
                   double* accum_rgb, rt_stats* stats);
 /* Same as rt_render but accum_rgb is DEVICE memory on the scene's device; the launches are
