@@ -42,15 +42,22 @@ const rt_camera* rth_scene_camera(const rth_scene* scene);
 uint32_t rth_scene_object_count(const rth_scene* scene);
 uint32_t rth_scene_bvh_calls(const rth_scene* scene);
 
-/* Replaces Texture::new_image (texture.rs:25-31: open + decode + to_rgb8) for the scenes that need an image
- * (scenes.rs:126, 178: assets/earthmap.jpg).  THE SIDE CHANNEL, stated plainly: no JPEG decoder is linked into this
- * layer, so the image is decoded once, offline, and handed over as RGB8 — either in memory (rth_scene_opts.texels;
- * Python ships raytracer_amd/assets/earthmap_rgb8.npz, a PIL decode of the reference's file) or as a binary PPM
- * (P6, maxval 255) read by this function.  Texel bytes may differ by +-1 LSB from what jpeg-decoder 0.1.22 yields
- * (IDCT rounding): parity unpinned against the crate.  *texels is malloc'ed RGB8 row-major [h][w][3]; release it
- * with rth_texture_free.  A missing or malformed file is RT_ERR_BAD_ARG (the reference panics, texture.rs:29).  */
+/* The texels of Texture::new_image (texture.rs:25-31: open + decode + to_rgb8) WITHOUT a decode: RGB8 in memory
+ * (rth_scene_opts.texels; Python ships raytracer_amd/assets/earthmap_rgb8.npz, a PIL decode of the reference's
+ * assets/earthmap.jpg) or a binary PPM (P6, maxval 255) read by this function.  For the reference's own file format see
+ * rth_texture_from_image_file below.  *texels is malloc'ed RGB8 row-major [h][w][3]; release it with
+ * rth_texture_free.  A missing or malformed file is RT_ERR_BAD_ARG (the reference panics, texture.rs:29).  */
 int rth_texture_from_rgb8_file(const char* path, uint32_t* width, uint32_t* height, uint8_t** texels);
 void rth_texture_free(uint8_t* texels);
+/* Replaces Texture::new_image (texture.rs:25-31) for the file the reference itself opens (scenes.rs:126, 178:
+ * assets/earthmap.jpg): a BASELINE JPEG (SOF0 / SOF1 Huffman, 8 bit, grey or YCbCr; csrc/host/jpeg_baseline.hpp) or a
+ * binary PPM, told apart by their first two bytes.  The reference decodes through image 0.23.13 -> jpeg-decoder 0.1.22
+ * (Cargo.lock), which are not in /root/reference: this decoder restates the published algorithm (T.81 Huffman decoding,
+ * the 12-bit fixed-point LL&M inverse DCT, JFIF colour conversion) and is pinned against an independent decode of
+ * the same file (tests/test_jpeg.py: 99.76 % of the texel bytes identical, 99.98 % within 1 LSB, none more than 3 off); against the crate itself parity is
+ * unpinned (+-1 LSB possible).  Progressive, arithmetic-coded, 12-bit and CMYK files are refused with
+ * RT_ERR_BAD_ARG and a reason.  Same ownership as above (rth_texture_free).                                        */
+int rth_texture_from_image_file(const char* path, uint32_t* width, uint32_t* height, uint8_t** texels);
 
 /* Replaces Camera::new (cam.rs:26-61). */
 int rth_camera_new(const double lookfrom[3], const double lookat[3], const double vup[3], double vfov,

@@ -104,7 +104,7 @@ RT_SYMBOLS = [
 RTH_SYMBOLS = [
     "rth_scene_build", "rth_scene_free", "rth_scene_desc", "rth_scene_camera", "rth_scene_object_count",
     "rth_scene_bvh_calls", "rth_camera_new", "rth_render", "rth_image_height", "rth_write_png", "rth_rotate",
-    "rth_bvh_axis", "rth_texture_from_rgb8_file", "rth_texture_free", "rth_kat_chacha", "rth_kat_chacha_quarter",
+    "rth_bvh_axis", "rth_texture_from_rgb8_file", "rth_texture_from_image_file", "rth_texture_free", "rth_kat_chacha", "rth_kat_chacha_quarter",
     "rth_kat_stdrng",
     "rth_last_error",
 ]
@@ -175,6 +175,7 @@ host.rth_image_height.argtypes = [C.c_uint32, C.c_double]
 host.rth_image_height.restype = C.c_uint32
 host.rth_write_png.argtypes = [C.c_char_p, _p, C.c_uint32, C.c_uint32]
 host.rth_texture_from_rgb8_file.argtypes = [C.c_char_p, _u32p, _u32p, C.POINTER(_u8p)]
+host.rth_texture_from_image_file.argtypes = host.rth_texture_from_rgb8_file.argtypes
 host.rth_texture_free.argtypes = [_u8p]
 host.rth_texture_free.restype = None
 host.rth_rotate.argtypes = [C.c_double, _p, _p, _p]

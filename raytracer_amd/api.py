@@ -40,10 +40,11 @@ def write_earthmap_ppm(path):
 
 
 def texture_from_file(path):
-    """Texture::new_image (texture.rs:25-31) through the host library: a binary PPM (P6, maxval 255) as RGB8
-    [h][w][3].  A missing or malformed file raises RtError(RT_ERR_BAD_ARG) where the reference panics."""
+    """Texture::new_image (texture.rs:25-31) through the host library: a baseline JPEG (what the reference opens:
+    assets/earthmap.jpg) or a binary PPM (P6, maxval 255), as RGB8 [h][w][3].  A missing, malformed or unsupported
+    (progressive, CMYK ...) file raises RtError(RT_ERR_BAD_ARG) where the reference panics."""
     w, h, px = C.c_uint32(), C.c_uint32(), F._u8p()
-    F.check_host(F.host.rth_texture_from_rgb8_file(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px)))
+    F.check_host(F.host.rth_texture_from_image_file(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px)))
     try:
         return np.ctypeslib.as_array(px, shape=(h.value, w.value, 3)).copy()
     finally:

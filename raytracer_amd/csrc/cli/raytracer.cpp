@@ -3,10 +3,10 @@
 // the GPU through include/rt.h.  Options after the reference's own are extensions and say so in --help.
 //
 // Differences a user can see: the PNG is written with stored deflate blocks (same pixels, larger file);
-// the earth texture is read from a binary PPM (`--earthmap`, default assets/earthmap.ppm, where the
-// reference opens assets/earthmap.jpg, scenes.rs:126) because no JPEG decoder is linked —
-// `python -c "import raytracer_amd as R; R.write_earthmap_ppm('assets/earthmap.ppm')"` writes it; the
-// reference's panics (bad numbers, unwritable output) are error messages with exit status 2 / 1.
+// the earth texture is opened where the reference opens it (assets/earthmap.jpg, scenes.rs:126) and decoded by the
+// host layer's baseline-JPEG decoder (rth_texture_from_image_file; texels within +-1 LSB of other decoders), or from
+// `--earthmap <file>` (a baseline JPEG or a binary PPM); the reference's panics (bad numbers, unwritable output,
+// missing texture) are error messages with exit status 2 / 1.
 #include <cctype>
 #include <cerrno>
 #include <chrono>
@@ -31,7 +31,7 @@ struct Opts {  // main.rs:28-49
   int device = 0;
   uint64_t seed = 1, scene_seed = 5, bvh_seed = 7;
   uint32_t n = 0;
-  std::string earthmap = "assets/earthmap.ppm";
+  std::string earthmap = "assets/earthmap.jpg";  // scenes.rs:126
 };
 
 const char* USAGE =
@@ -53,8 +53,8 @@ const char* USAGE =
     "        --scene-seed <n>      scene generator seed (scenes.rs:64 uses 5) [default: 5]\n"
     "        --bvh-seed <n>        BVH split-axis stream [default: 7]\n"
     "        --n <n>               scene 7 (bvh_stress): number of spheres\n"
-    "        --earthmap <file>     binary PPM (P6, maxval 255) of the earth texture, scenes 2, 4, 8, 11\n"
-    "                              [default: assets/earthmap.ppm]\n"
+    "        --earthmap <file>     the earth texture of scenes 2, 4, 8, 11: a baseline JPEG or a binary PPM (P6)\n"
+    "                              [default: assets/earthmap.jpg]\n"
     "    scenes: 0 random_scene, 1 two_spheres, 2 earth, 3 simple_light, 4 cube_scene, 6 cornell_box,\n"
     "            7 bvh_stress, 8 final_scene, 9 mixed_scene (test generator), 10 perlin_spheres and\n"
     "            11 final_scene with the Perlin sphere (extensions), anything else small_scene (main.rs:117-124)\n";
@@ -182,11 +182,8 @@ int main(int argc, char** argv) {
     ~TexelGuard() { rth_texture_free(p); }
   } texel_guard{texels};
   if (o.scene == 2 || o.scene == 4 || o.scene == 8 || o.scene == 11) {  // Texture::new_image (texture.rs:25-31, scenes.rs:126)
-    if (rth_texture_from_rgb8_file(o.earthmap.c_str(), &ro.scene.tex_width, &ro.scene.tex_height, &texels) != RT_OK) {
-      std::fprintf(stderr,
-                   "error: scene %u needs the earth texture: cannot read '%s' as a binary PPM (P6, maxval 255).\n"
-                   "       write it with: python -c \"import raytracer_amd as R; R.write_earthmap_ppm('assets/earthmap.ppm')\"\n",
-                   o.scene, o.earthmap.c_str());
+    if (rth_texture_from_image_file(o.earthmap.c_str(), &ro.scene.tex_width, &ro.scene.tex_height, &texels) != RT_OK) {
+      std::fprintf(stderr, "error: scene %u needs the earth texture (scenes.rs:126): %s\n", o.scene, rth_last_error());
       return 1;
     }
     ro.scene.texels = texels;

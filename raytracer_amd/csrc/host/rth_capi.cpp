@@ -1,4 +1,5 @@
 // C ABI of librt_host.so (include/rt_host.h).
+#include "jpeg_baseline.hpp"
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
@@ -98,6 +99,47 @@ int rth_texture_from_rgb8_file(const char* path, uint32_t* width, uint32_t* heig
   return RT_OK;
 }
 void rth_texture_free(uint8_t* texels) { std::free(texels); }
+
+int rth_texture_from_image_file(const char* path, uint32_t* width, uint32_t* height, uint8_t** texels) {
+  if (!path || !width || !height || !texels) return fail(RT_ERR_BAD_ARG, "rth_texture_from_image_file: null argument");
+  *texels = nullptr;
+  *width = *height = 0;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(RT_ERR_BAD_ARG, std::string("rth_texture_from_image_file: cannot open '") + path + "' (texture.rs:29 would panic)");
+  unsigned char magic[2] = {0, 0};
+  const size_t got = std::fread(magic, 1, 2, f);
+  if (got == 2 && magic[0] == 'P' && magic[1] == '6') {
+    std::fclose(f);
+    return rth_texture_from_rgb8_file(path, width, height, texels);
+  }
+  if (got != 2 || magic[0] != 0xFF || magic[1] != 0xD8) {
+    std::fclose(f);
+    return fail(RT_ERR_BAD_ARG, std::string("rth_texture_from_image_file: '") + path + "' is neither a JPEG nor a binary PPM (P6)");
+  }
+  std::vector<uint8_t> bytes;
+  std::fseek(f, 0, SEEK_END);
+  const long size = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  if (size > 0 && size < (1l << 30)) {
+    bytes.resize((size_t)size);
+    if (std::fread(bytes.data(), 1, bytes.size(), f) != bytes.size()) bytes.clear();
+  }
+  std::fclose(f);
+  if (bytes.empty()) return fail(RT_ERR_BAD_ARG, std::string("rth_texture_from_image_file: cannot read '") + path + "'");
+  try {
+    uint32_t w = 0, h = 0;
+    const std::vector<uint8_t> rgb = rth::jpeg::Decoder(bytes.data(), bytes.size()).decode(w, h);
+    uint8_t* buf = (uint8_t*)std::malloc(rgb.size());
+    if (!buf) return fail(RT_ERR_BAD_ARG, "rth_texture_from_image_file: out of memory");
+    std::memcpy(buf, rgb.data(), rgb.size());
+    *texels = buf;
+    *width = w;
+    *height = h;
+    return RT_OK;
+  } catch (const std::exception& e) {
+    return fail(RT_ERR_BAD_ARG, std::string("rth_texture_from_image_file: '") + path + "': " + e.what());
+  }
+}
 
 uint32_t rth_image_height(uint32_t image_width, double aspect_ratio) {
   double h = (double)image_width / aspect_ratio;  // `as u32` truncates and saturates

@@ -193,10 +193,10 @@ def test_no_gpu_means_an_error_not_a_cpu_fallback():
 
 
 def test_texture_file_side_channel(tmp_path):
-    """a29, Texture::new_image (texture.rs:25-31): the host layer decodes no JPEG; the image arrives as RGB8 in memory
-    or as a binary PPM through rth_texture_from_rgb8_file.  Round trip of the shipped earth texture, and the two
-    ways the reference would panic (missing file, scenes.rs:126; a scene that needs texels and gets none) come
-    back as RT_ERR_BAD_ARG through the library."""
+    """a29, Texture::new_image (texture.rs:25-31): the image arrives as RGB8 in memory, or from a file through
+    rth_texture_from_image_file (a baseline JPEG: tests/test_jpeg.py; or a binary PPM: here).  Round trip of the shipped
+    earth texture, and the two ways the reference would panic (missing file, scenes.rs:126; a scene that needs texels
+    and gets none) come back as RT_ERR_BAD_ARG through the library."""
     import raytracer_amd as R
     from raytracer_amd import _ffi as F
     tex = R.load_earthmap()
@@ -215,9 +215,12 @@ def test_texture_file_side_channel(tmp_path):
     (tmp_path / "short.ppm").write_bytes(raw[:1000])
     with pytest.raises(F.RtError, match="not a complete binary PPM"):
         R.texture_from_file(str(tmp_path / "short.ppm"))
-    (tmp_path / "jpeg.ppm").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
-    with pytest.raises(F.RtError, match="not a complete binary PPM"):
+    (tmp_path / "jpeg.ppm").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)  # a JPEG's first bytes, then nothing of one
+    with pytest.raises(F.RtError, match="truncated"):
         R.texture_from_file(str(tmp_path / "jpeg.ppm"))
+    (tmp_path / "png.ppm").write_bytes(b"\x89PNG\r\n" + b"\0" * 64)
+    with pytest.raises(F.RtError, match="neither a JPEG nor a binary PPM"):
+        R.texture_from_file(str(tmp_path / "png.ppm"))
     for sid in (2, 4, 8, 11):  # every scene that calls Texture::new_image
         o = F.RthSceneOpts()
         o.scene_id, o.rotate_bbox, o.aspect_ratio, o.scene_seed, o.bvh_seed = sid, -1, 1.5, 5, 7
