@@ -418,7 +418,9 @@ RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng
       h = complex_t(sc, ref_index(cur), r, t_min, closest, rng, t, cnt);
     else
       h = prim_t(sc, cur, r, inv_d, a, t_min, closest, t, cnt);
-    if (h && t < closest) {
+    // hittable.rs:405-411: the first record found is kept whatever its t (a NaN t from a NaN ray included — the
+    // reference returns it, and every later `right.t < left.t` is then false); a later one must be strictly closer
+    if (h && (best == REF_NONE || t < closest)) {
       closest = t;
       best = cur;
     }
@@ -447,7 +449,7 @@ RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng
         h = complex_t(sc, ref_index(cur), r, t_min, closest, rng, t, cnt);
       else
         h = prim_t(sc, cur, r, inv_d, a, t_min, closest, t, cnt);
-      if (h && t < closest) {
+      if (h && (best == REF_NONE || t < closest)) {
         closest = t;
         best = cur;
       }
