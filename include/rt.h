@@ -341,6 +341,11 @@ int rt_tonemap_device(int device, const float* accum_rgb_device, uint64_t n_pixe
 int rt_kat_sphere_uv(int device, uint32_t n, const double* p /*[n][3]*/, double* uv /*[n][2]*/, int use_f32);
 int rt_kat_rotate(int device, uint32_t n, const double* angle_rad, const double* axis /*[n][3]*/,
                   const double* v /*[n][3]*/, double* out /*[n][3]*/, int use_f32);
+/* The f64 kernels' transcendental functions as the device computes them: op 0 sin(a), 1 cos(a), 2 log(a),
+ * 3 atan2(a, b), 4 acos(a); n items (b is read for every op).  No counterpart in the reference: the f64 kernel follows
+ * the CPU oracle path for path EXCEPT where these differ from the host's libm in the last bit (alias.rs:78-90,
+ * hittable.rs:342, 530-540 call them); tests/test_gpu_kats.py measures how often that is.                        */
+int rt_kat_libm(int device, uint32_t op, uint32_t n, const double* a, const double* b, double* out);
 /* rounds: 7 = the generator of the per-path draw streams (Philox4x32-7), 10 = the generator of the
  * scene and BVH-axis streams (Philox4x32-10).  Both are pinned by Random123's published vectors.     */
 int rt_kat_philox(int device, uint32_t n, const uint32_t* ctr /*[n][4]*/, const uint32_t* key /*[n][2]*/,

@@ -1923,6 +1923,17 @@ __global__ void kat_sphere_uv_kernel(uint32_t n, const double* p, double* uv) {
   uv[2 * i] = (double)r.x;
   uv[2 * i + 1] = (double)r.y;
 }
+// The f64 kernels' transcendental functions (device libm), for tests that measure where they differ from the host's:
+// op 0 sin(a), 1 cos(a), 2 log(a), 3 atan2(a, b), 4 acos(a).
+#ifdef RT_DEFINE_LIBM_KAT  // (one definition: the f64 translation unit's)
+__global__ void kat_libm_kernel(uint32_t n, uint32_t op, const double* a, const double* b, double* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i], y = b[i];
+  out[i] = op == 0 ? sin(x) : op == 1 ? cos(x) : op == 2 ? log(x) : op == 3 ? atan2(x, y) : acos(x);
+}
+#endif
+
 template <typename R>
 __global__ void kat_rotate_kernel(uint32_t n, const double* angle, const double* axis, const double* v, double* out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

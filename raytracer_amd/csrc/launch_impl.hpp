@@ -224,6 +224,13 @@ hipError_t RT_CAT(launch_kat_rotate_, RT_SUFFIX)(uint32_t n, const double* angle
   return hipGetLastError();
 }
 
+#ifdef RT_DEFINE_LIBM_KAT  // (in the f64 translation unit: built like the audit kernels, contraction off)
+hipError_t launch_kat_libm(uint32_t n, uint32_t op, const double* a, const double* b, double* out, hipStream_t st) {
+  RT_LAUNCH(kat_libm_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, op, a, b, out);
+  return hipGetLastError();
+}
+#endif
+
 #ifdef RT_DEFINE_COMMON
 hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t* out, hipStream_t st) {
   uint64_t blocks = (n + 255) / 256;

@@ -1663,6 +1663,20 @@ int rt_kat_rotate(int device, uint32_t n, const double* angle, const double* axi
                     &c);
 }
 
+int rt_kat_libm(int device, uint32_t op, uint32_t n, const double* a, const double* b, double* out) {
+  if (!a || !b || !out || n == 0 || op > 4) return fail(RT_ERR_BAD_ARG, "rt_kat_libm: bad argument");
+  size_t ib[] = {n * sizeof(double), n * sizeof(double)};
+  const void* in[] = {a, b};
+  KatCtx c{n, (int)op};
+  return kat_common(device, ib, in, 2, n * sizeof(double), out,
+                    [](void** di, void* dout, void* ctx) -> hipError_t {
+                      auto* k = (KatCtx*)ctx;
+                      return launch_kat_libm(k->n, (uint32_t)k->variant, (const double*)di[0], (const double*)di[1],
+                                             (double*)dout, nullptr);
+                    },
+                    &c);
+}
+
 int rt_kat_philox(int device, uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t rounds, uint32_t* out) {
   if (!ctr || !key || !out || n == 0) return fail(RT_ERR_BAD_ARG, "rt_kat_philox: bad argument");
   if (rounds != 7 && rounds != 10)

@@ -5,4 +5,5 @@
 #define RT_HAS_LINEAR 0
 #define RT_EARLY_EXIT false
 #define RT_DEFINE_F64_FIX 1
+#define RT_DEFINE_LIBM_KAT 1
 #include "launch_impl.hpp"
