@@ -72,6 +72,10 @@ typedef struct rth_render_opts {   /* = struct Opts, main.rs:28-49, plus what ma
   int32_t device;                  /* GPU index; negative = every GPU of the node (rt_render_multi), as rayon
                                       takes every core (main.rs:157) */
   uint64_t seed;
+  uint32_t precision;              /* 0 = the f32 product kernels; 1 = the f64 audit kernels and an f64 tone map: the
+                                      reference's own arithmetic (alias.rs:4-7), pixel for pixel the CPU oracle's image up to
+                                      libm's last bit (one device only) */
+  uint32_t reserved;
 } rth_render_opts;
 
 /* Replaces main() from "World" to the put_pixel loop (main.rs:116-174): builds the scene,

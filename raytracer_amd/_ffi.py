@@ -92,6 +92,7 @@ class RthRenderOpts(C.Structure):
     _fields_ = [
         ("scene", RthSceneOpts), ("image_width", C.c_uint32), ("samples_per_pixel", C.c_uint32),
         ("max_depth", C.c_uint32), ("device", C.c_int32), ("seed", C.c_uint64),
+        ("precision", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 

@@ -277,7 +277,7 @@ def tonemap(accum, spp):
 
 
 def render(scene=3, image_width=1200, aspect_ratio=1.5, samples_per_pixel=500, max_depth=5, device=0, seed=1,
-           scene_seed=5, bvh_seed=7, n=0, texels=None):
+           scene_seed=5, bvh_seed=7, n=0, texels=None, f64=False):
     """main() of the reference (same option names and defaults as `struct Opts`, main.rs:28-49) minus
     the PNG save: returns (rgb8 [h][w][3], accum SUM float32 [h][w][3], stats dict)."""
     scene_id = SCENE_IDS[scene] if isinstance(scene, str) else int(scene)
@@ -300,6 +300,7 @@ def render(scene=3, image_width=1200, aspect_ratio=1.5, samples_per_pixel=500, m
     o.max_depth = max_depth
     o.device = device
     o.seed = seed
+    o.precision = 1 if f64 else 0  # the f64 audit kernels + f64 tone map: the reference's own arithmetic
     h = image_height(image_width, aspect_ratio)
     rgb8 = np.zeros((h, image_width, 3), dtype=np.uint8)
     accum = np.zeros((h, image_width, 3), dtype=np.float32)

@@ -29,6 +29,7 @@ struct Opts {  // main.rs:28-49
   uint32_t max_depth = 5;
   // extensions
   int device = 0;
+  unsigned precision = 0;  // --precision f32 | f64
   uint64_t seed = 1, scene_seed = 5, bvh_seed = 7;
   uint32_t n = 0;
   std::string earthmap = "assets/earthmap.jpg";  // scenes.rs:126
@@ -49,6 +50,8 @@ const char* USAGE =
     "    -s, --scene <scene>                            [default: 3]\n"
     "\nEXTENSIONS (not in the reference):\n"
     "        --device <n|all>      GPU to render on, or every GPU of the node (samples sharded) [default: 0]\n"
+    "        --precision <f32|f64> f32: the product kernels; f64: the audit kernels, the reference's own arithmetic\n"
+    "                              (slower; one device) [default: f32]\n"
     "        --seed <n>            Philox key of the per-path draws [default: 1]\n"
     "        --scene-seed <n>      scene generator seed (scenes.rs:64 uses 5) [default: 5]\n"
     "        --bvh-seed <n>        BVH split-axis stream [default: 7]\n"
@@ -144,6 +147,14 @@ int main(int argc, char** argv) {
         u32(d);
         o.device = (int)d;
       }
+    } else if (name == "--precision") {
+      const std::string v = need();
+      if (v == "f32")
+        o.precision = 0;
+      else if (v == "f64")
+        o.precision = 1;
+      else
+        usage_error("Invalid value for '" + name + "': '" + v + "' is not f32 or f64");
     } else if (name == "--seed") {
       u64(o.seed);
     } else if (name == "--scene-seed") {
@@ -193,6 +204,7 @@ int main(int argc, char** argv) {
   ro.max_depth = o.max_depth;
   ro.device = o.device;
   ro.seed = o.seed;
+  ro.precision = o.precision;
 
   std::vector<uint8_t> rgb8((size_t)image_width * image_height * 3);
   rt_stats st;

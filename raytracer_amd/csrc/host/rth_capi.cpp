@@ -4,6 +4,7 @@
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <vector>
 #include <stdexcept>
@@ -214,6 +215,37 @@ int rth_render(const rth_render_opts* o, uint8_t* rgb8, float* accum, uint32_t* 
   if (!acc) {
     local.resize((size_t)w * h * 3);
     acc = local.data();
+  }
+  if (o->precision > 1) {
+    rth_scene_free(hs);
+    return fail(RT_ERR_BAD_ARG, "rth_render: precision must be 0 (f32) or 1 (f64)");
+  }
+  if (o->precision == 1) {
+    // the audit kernels: sums in f64, divided and tone-mapped in f64 like main.rs:167, 51-63
+    if (o->device < 0) {
+      rth_scene_free(hs);
+      return fail(RT_ERR_BAD_ARG, "rth_render: the f64 kernels render on one device (device >= 0)");
+    }
+    std::vector<double> acc64((size_t)w * h * 3);
+    rt_scene* ds = nullptr;
+    rc = rt_scene_create(o->device, &hs->desc, &ds);
+    if (rc == RT_OK) {
+      rc = rt_render_f64(ds, &hs->camera, &p, acc64.data(), stats);
+      rt_scene_destroy(ds);
+    }
+    if (rc != RT_OK) {
+      g_err = std::string("rth_render: ") + rt_last_error();
+    } else {
+      for (size_t i = 0; i < acc64.size(); ++i) {
+        acc[i] = (float)acc64[i];
+        const double g = std::sqrt(acc64[i] / (double)p.spp);
+        uint8_t q = 0;  // (NaN as u8 = 0)
+        if (g == g) q = (uint8_t)((g < 0.0 ? 0.0 : (g > 0.9999 ? 0.9999 : g)) * 256.0);
+        rgb8[i] = q;
+      }
+    }
+    rth_scene_free(hs);
+    return rc;
   }
   if (o->device < 0) {
     // every GPU of the node, as rayon takes every core (main.rs:157): the samples are sharded by rt_render_multi;

@@ -87,6 +87,31 @@ def test_cli_renders_what_the_api_renders(tmp_path, scene, texture):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene", [6, 0, 3])
+def test_cli_in_the_references_precision_writes_the_oracles_image(tmp_path, scene):
+    """`--precision f64` (the audit kernels + an f64 tone map: main.rs:160-168, 51-63 in the reference's own arithmetic):
+    the PNG the command line writes is the CPU oracle's image of the same scene, seeds and sample count — pixel for
+    pixel, up to a quantisation step where libm's last bit differs."""
+    import oracle_ffi as O
+    os.makedirs(tmp_path / "renders")
+    w, asp, spp, depth = 72, 1.5, 8, 6
+    p = run("-s", str(scene), "-i", str(w), "-a", str(asp), f"--samples-per-pixel={spp}", "--max-depth", str(depth),
+            "--precision", "f64", "--seed", "3", cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr
+    with Image.open(tmp_path / "renders" / "image.png") as im:
+        got = np.asarray(im).astype(np.int32)
+    h = R.image_height(w, asp)
+    o, _, _ = O.OracleScene(scene, asp).render(w, h, spp, depth, seed=3)
+    g = np.sqrt(o / spp)
+    want = np.where(np.isnan(g), 0, np.clip(g, 0.0, 0.9999) * 256.0).astype(np.uint8).astype(np.int32)  # main.rs:51-63
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() <= 2e-3, ((got != want).mean(), np.abs(got - want).max())
+    # and through the Python form of main()
+    rgb8, _, _ = R.render(scene=scene, image_width=w, aspect_ratio=asp, samples_per_pixel=spp, max_depth=depth, seed=3, f64=True)
+    assert np.array_equal(rgb8.astype(np.int32), got)
+
+
+@pytest.mark.gpu
 def test_cli_missing_texture_and_missing_directory(tmp_path):
     p = run("-s", "2", "-i", "32", "--samples-per-pixel", "1", cwd=str(tmp_path))
     assert p.returncode == 1 and "earth texture" in p.stderr
