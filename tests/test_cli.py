@@ -108,7 +108,10 @@ def test_cli_in_the_references_precision_writes_the_oracles_image(tmp_path, scen
     assert np.abs(got - want).max() <= 1 and (got != want).mean() <= 2e-3, ((got != want).mean(), np.abs(got - want).max())
     # and through the Python form of main()
     rgb8, _, _ = R.render(scene=scene, image_width=w, aspect_ratio=asp, samples_per_pixel=spp, max_depth=depth, seed=3, f64=True)
-    assert np.array_equal(rgb8.astype(np.int32), got)
+    # (two f64 renders: a pixel's units are summed by atomics in the order they finish, so a channel may land on the
+    # other side of a quantisation step)
+    d = np.abs(rgb8.astype(np.int32) - got)
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-3
 
 
 @pytest.mark.gpu
