@@ -36,20 +36,23 @@ def test_grey_and_subsampled_files_decode(tmp_path):
     yy, xx = np.mgrid[0:70, 0:90]
     rgb = np.stack([xx * 2, yy * 3, (xx + yy)], -1).astype(np.uint8)
     for name, kw in (("grey.jpg", dict(mode="L")), ("s420.jpg", dict(subsampling=2)), ("s422.jpg", dict(subsampling=1)),
-                     ("s444.jpg", dict(subsampling=0))):
+                     ("s444.jpg", dict(subsampling=0)), ("rst_rows.jpg", dict(subsampling=0, restart_marker_rows=1)),
+                     ("rst_blocks.jpg", dict(subsampling=2, restart_marker_blocks=3))):
         path = str(tmp_path / name)
         im = Image.fromarray(rgb)
         if kw.get("mode") == "L":
             im = im.convert("L")
             im.save(path, quality=92)
         else:
-            im.save(path, quality=92, subsampling=kw["subsampling"])
+            im.save(path, quality=92, **kw)
+            if name.startswith("rst"):
+                assert b"\xff\xdd" in open(path, "rb").read()  # a DRI segment: the file has restart intervals
         got = R.texture_from_file(path)
         with Image.open(path) as back:
             want = np.asarray(back.convert("RGB"))
         assert got.shape == want.shape
         d = np.abs(got.astype(np.int32) - want.astype(np.int32))
-        limit = 2 if name in ("grey.jpg", "s444.jpg") else 12  # replication vs interpolation of the chroma planes
+        limit = 2 if name in ("grey.jpg", "s444.jpg", "rst_rows.jpg") else 12  # replication vs interpolation of the chroma planes
         assert d.max() <= limit, (name, d.max())
 
 
