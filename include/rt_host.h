@@ -86,7 +86,7 @@ int rth_render(const rth_render_opts* opts, uint8_t* rgb8, float* accum, uint32_
 uint32_t rth_image_height(uint32_t image_width, double aspect_ratio); /* main.rs:112 */
 
 /* Replaces image.save(opts.output) (main.rs:176) for the reference's default format: an 8-bit RGB PNG
- * (stored deflate blocks; decodes to exactly rgb8).  rgb8 is [height][width][3].                      */
+ * (row filters + one fixed-Huffman deflate block over LZ77 matches, csrc/host/png_write.hpp; decodes to exactly rgb8).  rgb8 is [height][width][3].                      */
 int rth_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
 
 /* Host-side known-answer hooks for the two functions the reference's tests pin. */

@@ -52,7 +52,7 @@ def texture_from_file(path):
 
 
 def write_png(path, rgb8):
-    """image.save(path) of main.rs:176 for an RGB8 image [h][w][3] (8-bit RGB PNG, stored deflate)."""
+    """image.save(path) of main.rs:176 for an RGB8 image [h][w][3] (8-bit RGB PNG; row filters + fixed-Huffman deflate)."""
     rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
     if rgb8.ndim != 3 or rgb8.shape[2] != 3:
         raise ValueError("rgb8 must be [h][w][3]")

@@ -2,7 +2,7 @@
 // librt_host.so / librt_hip.so: same options, defaults, stdout lines and output file; the render runs on
 // the GPU through include/rt.h.  Options after the reference's own are extensions and say so in --help.
 //
-// Differences a user can see: the PNG is written with stored deflate blocks (same pixels, larger file);
+// Differences a user can see: the PNG is compressed by the host layer's own small deflate (same pixels, other bytes than the image crate's);
 // the earth texture is opened where the reference opens it (assets/earthmap.jpg, scenes.rs:126) and decoded by the
 // host layer's baseline-JPEG decoder (rth_texture_from_image_file; texels within +-1 LSB of other decoders), or from
 // `--earthmap <file>` (a baseline JPEG or a binary PPM); the reference's panics (bad numbers, unwritable output,

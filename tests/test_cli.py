@@ -36,7 +36,7 @@ def test_degenerate_image_is_an_error_not_a_crash(tmp_path):
     assert p.returncode == 1 and p.stdout.splitlines()[0] == "1 0"  # main.rs:114 prints before anything else
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (23, 37), (200, 300)])  # the last one needs several stored blocks
+@pytest.mark.parametrize("shape", [(1, 1), (23, 37), (200, 300)])  # (decoded back with PIL)
 def test_png_roundtrip(tmp_path, shape):
     rgb8 = np.random.default_rng(shape[0]).integers(0, 256, size=shape + (3,), dtype=np.uint8)
     path = str(tmp_path / "img.png")
@@ -44,6 +44,20 @@ def test_png_roundtrip(tmp_path, shape):
     with Image.open(path) as im:
         assert im.mode == "RGB" and im.size == (shape[1], shape[0])
         assert np.array_equal(np.asarray(im), rgb8)
+
+
+def test_png_compresses_images_and_decodes_to_the_same_pixels(tmp_path):
+    """The writer's own deflate (row filters, LZ77 + fixed Huffman codes): smooth pictures shrink, every picture decodes
+    (with PIL's zlib) to exactly the bytes written; noise falls back to stored blocks (test_png_roundtrip)."""
+    yy, xx = np.mgrid[0:200, 0:300]
+    cases = {"gradient": np.stack([xx % 256, yy % 256, (xx + yy) % 256], -1).astype(np.uint8), "flat": np.full((64, 64, 3), 77, np.uint8),
+             "earth": R.load_earthmap(), "stripes": np.tile(np.array([[0, 0, 0], [255, 255, 255]], np.uint8), (50, 75, 1)).reshape(50, 150, 3)}
+    for name, rgb8 in cases.items():
+        path = str(tmp_path / (name + ".png"))
+        R.write_png(path, np.ascontiguousarray(rgb8))
+        with Image.open(path) as im:
+            assert np.array_equal(np.asarray(im.convert("RGB")), rgb8), name
+        assert os.path.getsize(path) < 0.6 * rgb8.size, (name, os.path.getsize(path), rgb8.size)
 
 
 def test_png_errors(tmp_path):
