@@ -684,6 +684,35 @@ RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, LinMasks masks,
   }
 }
 
+// The same leaf list for ANY precision, over the scene arrays themselves (`sc` may be a copy of the scene view whose
+// hot arrays point into LDS): every leaf of the tree in left-first DFS order, tested by the very code the
+// reference-order walk runs at a leaf (prim_t / complex_t), with the same shrinking t_max and the same acceptance
+// rule as traverse() — so the winner, its t (bit for bit) and the medium draws are the BVH walk's; what changes is the
+// work: no node tests, and the leaves a node box would have pruned are tested (and rejected).  The loop counter and
+// the leaf reference are wave-uniform: no traversal divergence, no stack.  This is what the f64 kernel walks on scenes
+// the f32 kernels take the leaf list for (same eligibility: verified-conservative boxes, <= LIN_MAX_LEAVES leaves).
+template <typename R, bool STATS>
+RT_DEV void traverse_leaves(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, R& closest, uint32_t& best,
+                            Cnt<STATS>& cnt) {
+  closest = Consts<R>::inf;
+  best = REF_NONE;
+  const Vec3<R> inv_d = inverse3(r.d);
+  const R a = sqrlen(r.d);
+  for (uint32_t k = 0; k < sc.n_leaf_list; ++k) {
+    const uint32_t ref = __builtin_amdgcn_readfirstlane(sc.leaf_list[k]);  // wave-uniform
+    R t;
+    bool h;
+    if (ref_kind(ref) == LEAF_COMPLEX)
+      h = complex_t(sc, ref_index(ref), r, t_min, closest, rng, t, cnt);
+    else
+      h = prim_t(sc, ref, r, inv_d, a, t_min, closest, t, cnt);
+    if (h && (best == REF_NONE || t < closest)) {  // as traverse(): hittable.rs:405-411
+      closest = t;
+      best = ref;
+    }
+  }
+}
+
 // ---- the winner's HitRecord (hittable.rs:17-40) -------------------------------------------
 template <typename R> struct HitRec {
   Vec3<R> p, normal;
@@ -797,26 +826,31 @@ RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>&
     h.p = madd(r.o, t, r.d);  // rigid maps: the world-space point is o + t d in any frame
     return;
   }
-  if (ref_kind(ref) != LEAF_COMPLEX) {
-    prim_record(sc, ref, r, t, force_uv, h);
-    return;
-  }
-  Complex cx = sc.complexes[ref_index(ref)];
+  // f64: the literal wrapper chain (hittable.rs:364-386), in three steps so that the wave runs ONE copy of the
+  // primitive's record code for bare and wrapped primitives alike (lanes at a wall and lanes at a rotated box run the
+  // cube code together): into the body's frame, the body's record, back out.
+  const bool is_cx = ref_kind(ref) == LEAF_COMPLEX;
+  Complex cx{};
   RayT<R> lr = r;
-  uint32_t n_outer = cx.medium_pos == REF_NONE ? cx.op_count : cx.medium_pos;
-  for (uint32_t k = 0; k < n_outer; ++k) {
-    uint32_t tag = sc.op_tag[cx.op_first + k];
-    Op<R> op = sc.ops[cx.op_first + k];
-    if (tag == OP_TRANSLATE) {
-      lr.o = lr.o - Vec3<R>(op.d[0], op.d[1], op.d[2]);
-    } else {
-      Quat<R> q{op.d[0], op.d[1], op.d[2], op.d[3]};
-      lr.o = qrotate(lr.o, q);
-      lr.d = qrotate(lr.d, q);
+  uint32_t n_outer = 0, body = ref;
+  if (is_cx) {
+    cx = sc.complexes[ref_index(ref)];
+    n_outer = cx.medium_pos == REF_NONE ? cx.op_count : cx.medium_pos;
+    body = cx.body;
+    for (uint32_t k = 0; k < n_outer; ++k) {
+      uint32_t tag = sc.op_tag[cx.op_first + k];
+      Op<R> op = sc.ops[cx.op_first + k];
+      if (tag == OP_TRANSLATE) {
+        lr.o = lr.o - Vec3<R>(op.d[0], op.d[1], op.d[2]);
+      } else {
+        Quat<R> q{op.d[0], op.d[1], op.d[2], op.d[3]};
+        lr.o = qrotate(lr.o, q);
+        lr.d = qrotate(lr.d, q);
+      }
     }
   }
-  if (cx.medium_pos == REF_NONE) {
-    prim_record(sc, cx.body, lr, t, force_uv, h);
+  if (!is_cx || cx.medium_pos == REF_NONE) {
+    prim_record(sc, body, lr, t, force_uv, h);
   } else {  // hittable.rs:349-362: arbitrary normal (1,0,0), uv (0,0), in the medium's frame
     h.p = madd(lr.o, t, lr.d);
     h.uv.x = R(0);
@@ -824,6 +858,7 @@ RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>&
     face_normal(lr.d, Vec3<R>(1, 0, 0), h);
     h.material = cx.material;
   }
+  if (!is_cx) return;
   h.object = cx.object;
   // unwind the outer wrappers, innermost first (hittable.rs:369-372, 378-385)
   for (uint32_t k = n_outer; k-- > 0;) {

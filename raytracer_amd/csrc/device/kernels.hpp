@@ -547,7 +547,9 @@ struct RenderArgs {
 // TRAV: 0 = the reference's left-first BVH walk, 1 = leaf list (small scenes), 2 = ordered BVH walk
 // run to completion per ray (kept as the A/B baseline of render_refill_kernel, which is what
 // LaunchShape::trav == 2 launches unless RT_ORDERED_NO_REFILL is set in the environment)
-constexpr int TRAV_REFERENCE = 0, TRAV_LINEAR = 1, TRAV_ORDERED = 2;
+// 3 = the leaf list over the scene arrays staged in LDS (traverse_leaves: any precision; what the f64 kernel runs on
+// leaf-list scenes)
+constexpr int TRAV_REFERENCE = 0, TRAV_LINEAR = 1, TRAV_ORDERED = 2, TRAV_LEAVES = 3;
 
 template <typename R, bool STATS, bool EARLY_EXIT, int TRAV, bool NOISE = false>
 __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : (sizeof(R) == 8 ? RT_RENDER_F64_MIN_WAVES : RT_RENDER_MIN_WAVES)) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
@@ -1216,15 +1218,49 @@ constexpr uint32_t UNIT_RING = 32;
 #endif
 // TRAV_REFERENCE (any precision): the same hand-out around the reference-order BVH walk — what scenes with
 // non-conservative boxes, RT_FLAG_FORCE_BVH and the f64 audit run on; EARLY_EXIT / NOISE as in render_kernel.
+// TRAV_LEAVES (f64): around traverse_leaves, the hot scene arrays staged in LDS once per workgroup.
+#ifndef RT_LEAVES_MIN_WAVES
+#define RT_LEAVES_MIN_WAVES 4
+#endif
 template <typename R, bool STATS, int TRAV = TRAV_LINEAR, bool EARLY_EXIT = true, bool NOISE = false>
-__global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WAVES : (sizeof(R) == 8 ? RT_RENDER_F64_MIN_WAVES : RT_RENDER_MIN_WAVES))
-    render_persist_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a, R* __restrict__ accum, DeviceStats* stats) {
-  constexpr bool LINEAR = TRAV == TRAV_LINEAR;
-  static_assert(TRAV == TRAV_LINEAR || TRAV == TRAV_REFERENCE, "leaf list or reference-order walk");
+__global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WAVES : TRAV == TRAV_LEAVES ? RT_LEAVES_MIN_WAVES : (sizeof(R) == 8 ? RT_RENDER_F64_MIN_WAVES : RT_RENDER_MIN_WAVES))
+    render_persist_kernel(SceneView<R> sc_in, CameraView<R> cam, RenderArgs a, R* __restrict__ accum, DeviceStats* stats) {
+  constexpr bool LINEAR = TRAV == TRAV_LINEAR, LEAVES = TRAV == TRAV_LEAVES;
+  static_assert(TRAV == TRAV_LINEAR || TRAV == TRAV_REFERENCE || TRAV == TRAV_LEAVES, "leaf list or reference-order walk");
   extern __shared__ uint32_t lds_stack[];  // TRAV_REFERENCE: the walk's stack
   [[maybe_unused]] uint32_t* stack = lds_stack + threadIdx.x;
   __shared__ Light<R> s_lights[LDS_MAX_LIGHTS];
   __shared__ float s_lin[LINEAR ? LIN_MAX_LEAVES * LIN_DWORDS : 1];
+  // TRAV_LEAVES: the arrays a leaf test reads (hittable.rs:42-91 flattened), staged so that the wave-uniform leaf loop
+  // reads LDS; `sc` is the scene view with those arrays re-pointed
+  __shared__ Real4<R> s_spheres[LEAVES ? STAGE_MAX_SPHERES : 1];
+  __shared__ Cube<R> s_cubes[LEAVES ? STAGE_MAX_CUBES : 1];
+  __shared__ Complex s_complexes[LEAVES ? STAGE_MAX_COMPLEXES : 1];
+  __shared__ Op<R> s_ops[LEAVES ? STAGE_MAX_OPS : 1];
+  __shared__ uint32_t s_op_tag[LEAVES ? STAGE_MAX_OPS : 1];
+  __shared__ uint32_t s_leaf_list[LEAVES ? LIN_MAX_LEAVES : 1];
+  // ... and the camera (24 doubles that are read once per sample): in LDS they cost no scalar registers between samples
+  __shared__ alignas(16) unsigned char s_cam_raw[LEAVES ? sizeof(CameraView<R>) : 16];
+  SceneView<R> sc = sc_in;
+  if constexpr (LEAVES) {
+    if (threadIdx.x == 0) *reinterpret_cast<CameraView<R>*>(s_cam_raw) = cam;
+    auto stage = [&](void* dst, const void* src, uint32_t bytes) {
+      for (uint32_t i = threadIdx.x; i < bytes / 4u; i += BLOCK)
+        reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+    };
+    stage(s_spheres, sc_in.spheres, sc_in.stage_spheres * (uint32_t)sizeof(Real4<R>));
+    stage(s_cubes, sc_in.cubes, sc_in.stage_cubes * (uint32_t)sizeof(Cube<R>));
+    stage(s_complexes, sc_in.complexes, sc_in.stage_complexes * (uint32_t)sizeof(Complex));
+    stage(s_ops, sc_in.ops, sc_in.stage_ops * (uint32_t)sizeof(Op<R>));
+    stage(s_op_tag, sc_in.op_tag, sc_in.stage_ops * 4u);
+    stage(s_leaf_list, sc_in.leaf_list, sc_in.n_leaf_list * 4u);
+    sc.spheres = s_spheres;
+    sc.cubes = s_cubes;
+    sc.complexes = s_complexes;
+    sc.ops = s_ops;
+    sc.op_tag = s_op_tag;
+    sc.leaf_list = s_leaf_list;
+  }
   __shared__ volatile uint32_t s_unit_xy[BLOCK / 64][UNIT_RING];  // tile origin x | y << 16
   __shared__ volatile uint32_t s_unit_k[BLOCK / 64][UNIT_RING];   // which sample range of the launch
   __shared__ uint32_t s_red[BLOCK / 64][2];                       // wave-wide max / min scratch
@@ -1343,7 +1379,10 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
         u = rdiv((R)px + ju, (R)(a.width - 1));
         v = rdiv((R)(a.height - py - 1) + jv, (R)(a.height - 1));
       }
-      ray = camera_ray(cam, u, v, rng);
+      if constexpr (LEAVES)
+        ray = camera_ray(*reinterpret_cast<const CameraView<R>*>(s_cam_raw), u, v, rng);
+      else
+        ray = camera_ray(cam, u, v, rng);
       thr = Vec3<R>(1, 1, 1);
       L = Vec3<R>(0, 0, 0);
       alive = true;
@@ -1359,6 +1398,8 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
         traverse_linear<STATS, true>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
       else
         traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
+    } else if constexpr (LEAVES) {
+      traverse_leaves(sc, ray, R(0.001), rng, t, best, cnt);
     } else {
       traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
     }

@@ -95,6 +95,9 @@ constexpr uint32_t LIN_FLAGS = 0, LIN_REF = 1, LIN_NID = 2, LIN_OBJECT = 3, LIN_
                    LIN_MAT = 24,  // Material<float> image: 12 dwords
                    LIN_INVEXT = 36;  // cube: 1 / (p1 - p0), 3 dwords
 constexpr uint32_t LINF_XF = 1u, LINF_CUBE = 2u, LINF_MEDIUM = 4u;
+// leaf list over the scene arrays (SceneView::leaf_list): what a workgroup stages in LDS at most
+constexpr uint32_t STAGE_MAX_SPHERES = 2 * LIN_MAX_LEAVES, STAGE_MAX_CUBES = LIN_MAX_LEAVES, STAGE_MAX_COMPLEXES = LIN_MAX_LEAVES,
+                   STAGE_MAX_OPS = 4 * LIN_MAX_LEAVES;
 template <typename R> struct Texture {
   uint32_t tag, odd, even, width, height, pad;
   uint64_t texel_offset;
@@ -130,6 +133,12 @@ template <typename R> struct SceneView {
                                // material): only the reference-order kernel's extension instantiation carries that code
   uint32_t linear_xf_mask, linear_cube_mask, linear_medium_mask;  // bit k = LINF_* of record k (kernel arguments:
                                                                   // scalar registers, no per-leaf flag read from LDS)
+  // Leaf list read straight from the arrays above (any precision; what the f64 kernel walks on small scenes): the
+  // n_leaf_list leaf references in BVH left-first DFS order, and how many records of the hot arrays a workgroup
+  // stages in LDS for it (spheres incl. baked, cubes, complexes, ops).  n_leaf_list = 0: not eligible.
+  const uint32_t* leaf_list;
+  uint32_t n_leaf_list;
+  uint32_t stage_spheres, stage_cubes, stage_complexes, stage_ops;
   uint32_t root;
   uint32_t root2;  // root of nodes2 (REF_NONE if the ordered walk is not available)
   uint32_t lights_kind, n_lights;

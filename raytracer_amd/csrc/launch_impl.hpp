@@ -42,10 +42,6 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   a.wave_tiles_x = shape.wave_tiles_x;
   a.wave_tiles = shape.wave_tiles;
   a.total_units = shape.total_units;
-  a.leaf_shift = shape.leaf_shift;
-  a.direct_accum = shape.direct_accum;
-  a.xcd_chunk = shape.xcd_chunk;
-  a.tile_band = shape.tile_band;
 #if RT_HAS_LINEAR
   if (shape.trav == TRAV_LINEAR && shape.unit_samples > 0) {  // persistent form: grid = workers, not tiles
     if (stats)
@@ -104,6 +100,17 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   // (rt_api.hip routes those here) so that no other kernel pays registers for it.
   constexpr bool F64 = sizeof(RT_REAL) == 8;
   if constexpr (F64) {
+    // leaf-list scenes (rt_api.hip: make_shape): the leaf list over the scene arrays, persistent form, without the
+    // extension code (scenes that use an extension take the reference-order kernel below)
+    if (shape.trav == TRAV_LEAVES && shape.unit_samples > 0 && !sc.has_noise) {
+      if (stats)
+        RT_LAUNCH((render_persist_kernel<RT_REAL, true, TRAV_LEAVES, RT_EARLY_EXIT, false>), grid, block, 0, st, sc, cam, a, accum,
+                  dstats);
+      else
+        RT_LAUNCH((render_persist_kernel<RT_REAL, false, TRAV_LEAVES, RT_EARLY_EXIT, false>), grid, block, 0, st, sc, cam, a, accum,
+                  dstats);
+      return hipGetLastError();
+    }
     if (shape.trav == TRAV_REFERENCE && shape.unit_samples > 0) {  // persistent form of the audit kernel (rt_api.hip: make_shape)
       if (stats)
         RT_LAUNCH((render_persist_kernel<RT_REAL, true, TRAV_REFERENCE, RT_EARLY_EXIT, true>), grid, block, lds, st, sc, cam, a,

@@ -437,7 +437,19 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
     }
   }
   UP(linear_rec, linear_rec)
+  // leaf list over the scene arrays (traverse_leaves: the f64 kernel's walk on leaf-list scenes); eligible when the
+  // arrays a leaf test reads fit the LDS staging area
+  std::vector<uint32_t> leaf_list;
+  if (!linear.empty() && spheres.size() <= STAGE_MAX_SPHERES && cubes.size() <= STAGE_MAX_CUBES &&
+      complexes.size() <= STAGE_MAX_COMPLEXES && ops.size() <= STAGE_MAX_OPS)
+    for (uint32_t ref : linear) leaf_list.push_back(f32_ref(ref));
+  UP(leaf_list, leaf_list)
 #undef UP
+  s.view.n_leaf_list = (uint32_t)leaf_list.size();
+  s.view.stage_spheres = (uint32_t)spheres.size();
+  s.view.stage_cubes = (uint32_t)cubes.size();
+  s.view.stage_complexes = (uint32_t)complexes.size();
+  s.view.stage_ops = (uint32_t)ops.size();
   s.view.n_linear = sizeof(R) == 4 ? (uint32_t)linear.size() : 0u;
   s.view.has_noise = 0;
   for (uint32_t i = 0; i < d.n_textures; ++i)
@@ -895,8 +907,14 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   LaunchShape sh;
   sh.trav = 0;  // the reference's left-first walk: always valid
   // (a scene with a Perlin texture, an extension, renders on the reference-order kernel: see launch_impl.hpp)
-  if (f32_fast && !s->f32.view.has_noise && s->boxes_conservative && cam && cam->time_open >= s->safe_t_lo && cam->time_close <= s->safe_t_hi)
+  const bool fast_ok = f32_fast && s->boxes_conservative && cam && cam->time_open >= s->safe_t_lo && cam->time_close <= s->safe_t_hi;
+  if (!f64 && fast_ok && !s->f32.view.has_noise)
     sh.trav = s->f32.view.n_linear > 0 ? 1 : (s->f32.ordered_root != RT_REF_NONE ? 2 : 0);
+  // f64: leaf-list scenes walk the leaf list too (traverse_leaves: same winners, t and draws as the reference-order
+  // walk, no node tests); RT_FLAG_FORCE_BVH / RT_F64_NO_LEAVES=1 keep the reference-order walk (A/B, work counting)
+  static const bool f64_no_leaves = getenv("RT_F64_NO_LEAVES") != nullptr;
+  if (f64 && fast_ok && !f64_no_leaves && !s->f64.view.has_noise && s->f64.view.n_leaf_list > 0 && max_depth > 0 && n_samples > 0)
+    sh.trav = 3;
   uint32_t tx = (w + 15) / 16, ty = (h + 15) / 16;
   sh.tiles = tx * ty;
   sh.stack_depth = sh.trav == 2 ? std::max(s->f32.ordered_height, 1u) : s->stack_depth;
@@ -969,8 +987,9 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   // workgroup per (tile, split) (A/B).  Not for the f32 reference-order kernel: its jobs are short-path scenes
   // (the reference's default job, depth 5: 35.9 ms as a grid, 38.2 ms at best in this form).
   static const bool ref_grid = getenv("RT_REF_GRID") != nullptr;
-  if (sh.trav == 0 && f64 && !ref_grid && max_depth > 0 && n_samples > 0) {
-    const uint32_t auto_unit = std::min(8u, std::max(2u, n_samples / 16));
+  if ((sh.trav == 0 || sh.trav == 3) && f64 && (!ref_grid || sh.trav == 3) && max_depth > 0 && n_samples > 0) {
+    // (leaf-list form at the metric's 4096 spp, units of 16 / 32 / 64 / 128 / 256 samples: 1511 / 1518 / 1545 / 1603 / 1751 ms)
+    const uint32_t auto_unit = sh.trav == 3 ? std::min(16u, std::max(2u, n_samples / 32)) : std::min(8u, std::max(2u, n_samples / 16));
     sh.unit_samples = std::max(1u, std::min(us ? (uint32_t)std::max(1, atoi(us)) : auto_unit, n_samples));
     sh.wave_tiles_x = (w + 7) / 8;
     sh.wave_tiles = sh.wave_tiles_x * ((h + 7) / 8);
@@ -981,6 +1000,7 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
       sh.splits = 1;
     } else {
       sh.unit_samples = 0;
+      sh.trav = 0;  // (the leaf-list form exists as a persistent kernel only)
     }
   }
   // Ordered-walk scenes: the same, with the refill kernel's job sharing (render_units_kernel).  RT_REFILL_GRID keeps
@@ -1219,8 +1239,7 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
   if (p->spp == 0 && !accumulate) HIP_TRY(launch_zero(d_accum, accum_bytes, stream));
   while (done < p->spp) {
     uint32_t n = std::min(per_launch, p->spp - done);
-    LaunchShape sh = make_shape(s, p->width, p->height, n, sizeof(R) == 4 && !(p->flags & RT_FLAG_FORCE_BVH), cam, p->max_depth,
-                                sizeof(R) == 8);
+    LaunchShape sh = make_shape(s, p->width, p->height, n, !(p->flags & RT_FLAG_FORCE_BVH), cam, p->max_depth, sizeof(R) == 8);
     int acc = (accumulate || !first) ? 1 : 0;
     if ((sh.splits > 1 || sh.unit_samples > 0) && !acc) HIP_TRY(launch_zero(d_accum, accum_bytes, stream));
     if (sh.unit_samples > 0 && !slots && !first) HIP_TRY(launch_zero(&s->dstats->unit_counter, sizeof(unsigned int), stream));

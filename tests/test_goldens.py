@@ -88,7 +88,9 @@ def test_hip_f64_image_equals_golden(name):
     sid, asp, n, depth = scene_args(name)
     ds = R.DeviceScene(R.HostScene(sid, asp, n=n), 0)
     h = R.image_height(W, asp)
-    img, st = ds.render(W, h, SPP, depth, seed=SEED, sample_offset=OFFSET, stats=True, f64=True)
+    # (RT_FLAG_FORCE_BVH: the reference-order walk, whose traversal counters are the oracle's; the default f64 walk of
+    # leaf-list scenes is checked against it in test_gpu_parity.py)
+    img, st = ds.render(W, h, SPP, depth, seed=SEED, sample_offset=OFFSET, stats=True, f64=True, force_bvh=True)
     gold = G[f"{name}/image_sum"]
     fin = np.isfinite(gold) & np.isfinite(img)
     assert (np.isfinite(gold) == np.isfinite(img)).mean() >= 0.999

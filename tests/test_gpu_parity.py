@@ -80,21 +80,33 @@ def test_primary_hits_f32(name, w, earthmap):
                                   "small_scene", "cornell_box", "final_scene", "perlin_spheres", "final_scene_perlin",
                                   "cornell_box_area", "area_light_plate", "random_scene_stdrng", "area_light_list"])
 def test_render_f64_follows_oracle_path_for_path(name, earthmap):
+    """Both f64 walks against the oracle (main.rs:65-105 + hittable.rs:208-415), same seed: the reference-order BVH
+    walk (RT_FLAG_FORCE_BVH: every work counter identical, nodes and primitive tests included) and the walk
+    rt_render_f64 takes by default — the leaf list on leaf-list scenes (no node tests, every leaf tested: only the
+    traversal counters differ), the reference-order walk elsewhere."""
     hs, ds, os_, h, depth = _pair(name, earthmap)
     spp = 8
-    g, gst = ds.render(W, h, spp, depth, seed=11, sample_offset=5, stats=True, f64=True)
     o, ocnt, _ = os_.render(W, h, spp, depth, seed=11, sample_offset=5)
-    fin = np.isfinite(o) & np.isfinite(g)
-    assert (np.isfinite(o) == np.isfinite(g)).mean() >= 0.999
-    err = np.abs(g - o)[fin] / (1.0 + np.abs(o[fin]))
-    # same draws, same branches; differences come from last-ulp libm results and the iterative vs
-    # recursive product order — except for the rare path where such an ulp flips a branch
-    assert np.quantile(err, 0.999) <= 1e-9, f"{name}: err q99.9 {np.quantile(err, 0.999)}"
-    assert (err > 1e-9).mean() <= 1e-3
-    # identical work counters (the audit kernel does not early-exit)
-    for k in ("rays", "nodes_visited", "sphere_tests", "cube_tests", "closest_hits", "diffuse_vertices",
-              "specular_vertices", "emitter_hits", "misses", "light_probes", "medium_probes"):
-        assert abs(gst[k] - ocnt[k]) <= 1e-4 * max(1, ocnt[k]), (name, k, gst[k], ocnt[k])
+    leaf_list_scene = None
+    for force_bvh in (True, False):
+        g, gst = ds.render(W, h, spp, depth, seed=11, sample_offset=5, stats=True, f64=True, force_bvh=force_bvh)
+        fin = np.isfinite(o) & np.isfinite(g)
+        assert (np.isfinite(o) == np.isfinite(g)).mean() >= 0.999
+        err = np.abs(g - o)[fin] / (1.0 + np.abs(o[fin]))
+        # same draws, same branches; differences come from last-ulp libm results and the iterative vs
+        # recursive product order — except for the rare path where such an ulp flips a branch
+        assert np.quantile(err, 0.999) <= 1e-9, f"{name}: err q99.9 {np.quantile(err, 0.999)}"
+        assert (err > 1e-9).mean() <= 1e-3
+        # identical work counters (the f64 kernels do not early-exit)
+        keys = ("rays", "closest_hits", "diffuse_vertices", "specular_vertices", "emitter_hits", "misses", "light_probes")
+        if force_bvh:
+            keys += ("nodes_visited", "sphere_tests", "cube_tests", "medium_probes")
+        for k in keys:
+            assert abs(gst[k] - ocnt[k]) <= 1e-4 * max(1, ocnt[k]), (name, force_bvh, k, gst[k], ocnt[k])
+        if not force_bvh:
+            leaf_list_scene = hs.desc.n_nodes > 0 and gst["nodes_visited"] == 0
+    if name in ("cornell_box", "small_scene", "two_spheres"):
+        assert leaf_list_scene, f"{name}: rt_render_f64 did not take the leaf list"
 
 
 def _psnr(a, b):
