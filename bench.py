@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s, Cornell box 1024x1024 at 4096 spp, depth 50 (BASELINE.json configs[1]).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--precision f64|f32] [--scaling weak|strong] [--config C5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one full pass of the hot path over the workload: every rank renders `spp` samples of every
-pixel of the Cornell box into an HBM-resident accumulator (rt_render_device), then (N > 1) one RCCL
-sum all-reduce merges the accumulators, then the image is tonemapped on the device.  Weak scaling:
-per-GPU work is fixed (4096 spp per GPU), the merged image has N x 4096 spp.
+A step = one full pass of the hot path over the workload: every rank renders its samples of every pixel of the
+Cornell box into an HBM-resident accumulator, then (N > 1) one RCCL sum all-reduce merges the accumulators, then the
+image is tonemapped on the device.
+  * --precision f64 (default): rt_render_f64_device — the reference computes in f64 throughout (alias.rs:4-7), so
+    this is the line the metric is quoted on (`dtype` "f64"); the kernel follows the CPU oracle path for path.
+    --precision f32: rt_render_device, the f32 product kernel (narrower than the reference's arithmetic).
+  * --scaling weak (default): every GPU renders --spp samples per step (the merged image has N x spp);
+    --scaling strong: the step's --spp samples are split over the ranks by shard_samples (north_star's
+    "a 1024^2 render at 4096 spp on 8 GPUs"; --config C5 = 3840x2160, 65536 spp, strong: BASELINE configs[4]).
 Rank 0 prints ONE JSON line.  At N = 1 the line also carries
-  * `f64_leg`: the same workload on the f64 audit kernel (rt_render_f64_device) at a stated, smaller spp —
-    the reference computes in f64 (alias.rs:4-7), this is the precision-matched throughput;
+  * `f32_leg`: the same workload on the f32 product kernel, with its own roofline (a peer line, not the metric:
+    its arithmetic is narrower than the reference's);
   * `cpu_baseline`: the CPU oracle timed on this box's host cores on a bounded sample of the workload;
-  * `other_configs`: one-GPU lines for BASELINE.json configs C1 / C3 / C4 at bounded spp.
+  * `other_configs`: one-GPU lines for BASELINE.json configs C1 / C3 / C4 (+ a scene that outgrows the Infinity
+    Cache) at bounded spp.
 `--gpus N` with N > 1 from a bare shell (no WORLD_SIZE) starts the N ranks itself, before any GPU call.
 """
 import argparse
@@ -37,6 +43,9 @@ COST = {
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: vector FP32 peak (= FP32 MFMA peak)
 PEAK_FP64_VALU_TFLOPS = 78.6    # vector FP64: half the FP32 rate
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+MALL_GATHER_GBPS = 8600.0       # MI355X_MICROARCH.md (L2 section): measured random-row gather from a 38 MB table that
+                                # sits in the 256 MiB Infinity Cache (151 MB table: 7400-7900)
+INFINITY_CACHE_BYTES = 256 << 20
 METRIC = "Mrays/s (whole node) 1/2/4/8 MI355X, Cornell box 1024² 4096spp"
 
 
@@ -109,78 +118,112 @@ class Workload:
         self.hs = R.HostScene(scene, aspect, n=n)
         self.ds = R.DeviceScene(self.hs, device)
         self.device = device
-        dev = torch.device("cuda", device)
-        self.accum = torch.zeros((self.height, width, 3), dtype=torch.float32, device=dev)
-        self.rgb8 = torch.zeros((self.height, width, 3), dtype=torch.uint8, device=dev)
+        self.dev = torch.device("cuda", device)
+        self.accum = torch.zeros((self.height, width, 3), dtype=torch.float32, device=self.dev)
+        self._accum64 = None
+        self.rgb8 = torch.zeros((self.height, width, 3), dtype=torch.uint8, device=self.dev)
         self.stream = torch.cuda.current_stream().cuda_stream
 
-    def scene_bytes(self):
-        d = self.hs.desc
-        return 32 * d.n_nodes + 16 * d.n_spheres + 48 * d.n_mspheres + 32 * d.n_cubes + 128 * d.n_complex
+    def accum_for(self, f64):
+        if not f64:
+            return self.accum
+        if self._accum64 is None:
+            self._accum64 = self.torch.zeros((self.height, self.width, 3), dtype=self.torch.float64, device=self.dev)
+        return self._accum64
 
-    def counted(self, depth, f64=False, accum_ptr=None):
+    def scene_bytes(self):
+        """what the f32 product walk of this scene touches: the reference's tree (32-B nodes) for leaf-list scenes,
+        the library's own SAH tree (64-B two-child nodes, one per leaf) for the ordered walk, plus the primitives"""
+        d = self.hs.desc
+        leaves = d.n_spheres + d.n_mspheres + d.n_cubes + d.n_complex
+        node_bytes = 32 * d.n_nodes if d.n_nodes < 64 else 64 * max(0, leaves - 1)
+        return node_bytes + 16 * d.n_spheres + 48 * d.n_mspheres + 32 * d.n_cubes + 128 * d.n_complex
+
+    def counted(self, depth, f64=False):
         """Algorithmic work per ray from a counted pass of the same launch shape at low spp.  Small scenes run the
-        leaf-list walk, which visits no nodes: their work is counted on the reference-order BVH walk
-        (RT_FLAG_FORCE_BVH); larger scenes are counted on the walk they run."""
+        leaf list, which visits no nodes: their work is counted on the reference-order BVH walk of the same
+        precision (RT_FLAG_FORCE_BVH: the reference algorithm's own node and primitive tests); larger scenes are
+        counted on the walk they run."""
         c_spp = 16 if self.hs.desc.n_nodes < 4096 else 2
-        ptr = accum_ptr if accum_ptr is not None else self.accum.data_ptr()
+        ptr = self.accum_for(f64).data_ptr()
         st = self.ds.render_device(ptr, self.width, self.height, c_spp, depth, seed=1, sample_offset=0,
                                    spp_per_launch=c_spp, stream=self.stream, stats=True, f64=f64)
         on = "the executed walk (box tests count as nodes)"
         if st["nodes_visited"] == 0 and self.hs.desc.n_nodes > 0:
             st = self.ds.render_device(ptr, self.width, self.height, c_spp, depth, seed=1, sample_offset=0,
-                                       spp_per_launch=c_spp, stream=self.stream, stats=True, force_bvh=True)
-            on = "reference-order BVH walk of the same scene (RT_FLAG_FORCE_BVH)"
+                                       spp_per_launch=c_spp, stream=self.stream, stats=True, force_bvh=True, f64=f64)
+            on = "reference-order BVH walk of the same scene and precision (RT_FLAG_FORCE_BVH)"
         flops, byts = algorithmic_per_ray(st, self.width * self.height, st["launches"])
         return flops, byts, on
 
-    def kernel_name(self, counted_on):
+    def kernel_name(self, counted_on, f64):
         d = self.hs.desc
-        if "RT_FLAG_FORCE_BVH" in counted_on or d.n_nodes == 0:
-            return "render_persist_kernel"
-        return "render_units_kernel"
+        small = "RT_FLAG_FORCE_BVH" in counted_on or d.n_nodes == 0
+        if f64:
+            return "render_persist_kernel<double, ..., TRAV_LEAVES>" if small else "render_persist_kernel<double, ..., TRAV_REFERENCE>"
+        return "render_persist_kernel<float, ..., TRAV_LINEAR>" if small else "render_units_kernel"
 
 
-def roofline(wl, depth, rays, kernel_ms, launches, workload_key):
-    flops_per_ray, bytes_per_ray, counted_on = wl.counted(depth)
+def roofline(wl, depth, rays, kernel_ms, launches, workload_key, f64=False):
+    flops_per_ray, bytes_per_ray, counted_on = wl.counted(depth, f64=f64)
     avg_launch_ms = kernel_ms / max(1, launches)
     rays_per_launch = rays / max(1, launches)
     tflops = flops_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e12
     gbps = bytes_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9
-    valu_frac, hbm_frac = tflops / PEAK_FP32_VALU_TFLOPS, gbps / PEAK_HBM_GBPS
-    # Which roof binds (SURVEY.md §8d): a scene whose nodes + primitives fit in one XCD's 4 MiB L2 (here: in LDS)
-    # never streams from HBM — its algorithmic bytes are served on-chip and the vector-FP32 issue rate is the
-    # roof; a scene larger than that is priced against HBM.
+    valu_peak = PEAK_FP64_VALU_TFLOPS if f64 else PEAK_FP32_VALU_TFLOPS
+    valu_frac, hbm_frac = tflops / valu_peak, gbps / PEAK_HBM_GBPS
+    # Which roof binds (SURVEY.md 8d): a scene whose nodes + primitives fit in one XCD's 4 MiB L2 (here: in LDS)
+    # never streams from HBM — its algorithmic bytes are served on-chip and the vector issue rate of the kernel's
+    # arithmetic type is the roof; a larger scene is priced against the memory system.
     scene_bytes = wl.scene_bytes()
     tr = measured_traffic(workload_key)
     traffic = tr[0].get("bytes_per_launch") if tr else None
     if scene_bytes <= 4 << 20:
-        r = {"bound": "valu_fp32", "achieved": tflops, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": valu_frac}
+        r = {"bound": "valu_fp64" if f64 else "valu_fp32", "achieved": tflops, "peak": valu_peak, "unit": "TFLOP/s",
+             "frac": valu_frac}
     else:
-        r = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_frac}
+        # Memory-bound scenes.  Algorithmic bytes per second can exceed what HBM delivers when the scene sits in the
+        # 256 MiB Infinity Cache (the cost model prices cache-served bytes): such a figure is not a utilisation.  With
+        # a committed PMC summary, `achieved` is the MEASURED fabric-side traffic of a launch / its duration (what left
+        # the L2s: Infinity-Cache hits included, so an upper bound on the HBM share) and `frac` = that / the HBM peak,
+        # never above 1 by construction of the peak; the algorithmic rate stays beside it.  Without a summary,
+        # `achieved` is the algorithmic rate, capped for `frac` at the on-die gather rate the guide measures.
+        if traffic is not None:
+            measured = traffic / (avg_launch_ms * 1e-3) / 1e9
+            r = {"bound": "hbm", "achieved": measured, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": measured / PEAK_HBM_GBPS,
+                 "achieved_basis": "measured fabric-side traffic per launch (FETCH_SIZE + WRITE_SIZE) / launch duration"}
+        else:
+            r = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": min(1.0, hbm_frac),
+                 "achieved_basis": "algorithmic bytes (no PMC summary for this workload: frac capped at 1)"}
+        r["cache_resident"] = scene_bytes <= INFINITY_CACHE_BYTES
+        r["frac_of_on_die_gather_rate"] = gbps / MALL_GATHER_GBPS
+        r["on_die_gather_rate_gbps"] = MALL_GATHER_GBPS
     r["traffic"] = traffic
     if tr:
         r["traffic_source"] = tr[1]
         r["traffic_note"] = tr[0].get("note")
+        for k in ("l2_hit_rate", "fetch_bytes_per_launch", "write_bytes_per_launch"):
+            if k in tr[0]:
+                r[k] = tr[0][k]
     r.update({
-        "kernel": wl.kernel_name(counted_on), "algorithmic_work_counted_on": counted_on,
+        "kernel": wl.kernel_name(counted_on, f64), "algorithmic_work_counted_on": counted_on,
         "avg_launch_ms": avg_launch_ms, "launches": launches,
         "algorithmic_flops_per_ray": flops_per_ray, "algorithmic_bytes_per_ray": bytes_per_ray,
         "algorithmic_tflops": tflops, "algorithmic_gbps": gbps,
-        "frac_valu_fp32": valu_frac, "frac_hbm": hbm_frac, "scene_bytes": scene_bytes,
-        "note": "no MFMA on this path; the binding peak is vector FP32 (157.3 TFLOP/s), not a matrix peak",
+        "frac_valu": valu_frac, "algorithmic_gbps_over_hbm_peak": hbm_frac, "scene_bytes": scene_bytes,
+        "note": "no MFMA on this path; the compute peak is the vector rate of the kernel's arithmetic type "
+                f"({valu_peak} TFLOP/s), not a matrix peak",
     })
-    if r["bound"] == "hbm" and scene_bytes <= 200 << 20:
-        r["note"] += ("; this scene fits the 256 MiB Infinity Cache, so its algorithmic bytes are largely served on-die "
-                      "(L1/L2/MALL): frac prices them against HBM as the contract asks and can exceed 1 -- it is not an "
-                      "HBM utilisation (see profiles/ for EA counters)")
+    if r["bound"] == "hbm" and r.get("cache_resident"):
+        r["note"] += ("; this scene fits the 256 MiB Infinity Cache: its algorithmic bytes are largely served on-die "
+                      "(L1/L2/MALL), see frac_of_on_die_gather_rate; frac is the measured fabric-side share of the HBM peak")
     return r
 
 
-def time_renders(wl, spp, depth, steps, warmup, spp_per_launch=0, f64=False, accum=None, base_step=0):
+def time_renders(wl, spp, depth, steps, warmup, spp_per_launch=0, f64=False, base_step=0):
     """`warmup` untimed + `steps` timed renders on one GPU; returns (seconds, rays, kernel_ms, launches, nonfinite)."""
     torch = wl.torch
-    ptr = (accum if accum is not None else wl.accum).data_ptr()
+    ptr = wl.accum_for(f64).data_ptr()
     for i in range(warmup):
         wl.ds.render_device(ptr, wl.width, wl.height, spp, depth, seed=1, sample_offset=(base_step + i) * spp,
                             spp_per_launch=spp_per_launch, stream=wl.stream, f64=f64)
@@ -200,84 +243,116 @@ def time_renders(wl, spp, depth, steps, warmup, spp_per_launch=0, f64=False, acc
     return time.perf_counter() - t0, rays, kernel_ms, launches, nonfinite
 
 
-def f64_leg(wl, args):
-    """The same workload on the f64 audit kernel (reference-order walk, contraction off: the kernel that follows
-    the CPU oracle path for path): the throughput at the reference's own precision."""
-    torch = wl.torch
-    acc64 = torch.zeros((wl.height, wl.width, 3), dtype=torch.float64, device=wl.accum.device)
-    spp = args.f64_spp
-    secs, rays, kernel_ms, launches, _ = time_renders(wl, spp, args.max_depth, args.f64_steps, 1, f64=True, accum=acc64)
-    flops_per_ray, bytes_per_ray, _ = wl.counted(args.max_depth, f64=True, accum_ptr=acc64.data_ptr())
-    samples = float(wl.width) * wl.height * spp * args.f64_steps
-    avg_ms = kernel_ms / max(1, launches)
-    tflops = flops_per_ray * (rays / max(1, launches)) / (avg_ms * 1e-3) / 1e12
-    return {
-        "dtype": "f64", "entry": "rt_render_f64_device", "kernel": "render_persist_kernel<double, ..., TRAV_REFERENCE>",
+def workload_key(scene, width, height, spp, depth, n=0, f64=False):
+    """The key a profiles/*_traffic.json names its workload by (f32 keys are round 2's; f64 ones end in ', f64')."""
+    return f"{scene} {width}x{height}, {spp} spp, max depth {depth}" + (f", n={n}" if n else "") + (", f64" if f64 else "")
+
+
+def peer_leg(wl, args, f64):
+    """The same workload, same spp, on the kernel of the OTHER precision, with its own roofline."""
+    spp, steps = args.spp, args.leg_steps
+    secs, rays, kernel_ms, launches, nonfinite = time_renders(wl, spp, args.max_depth, steps, 1, f64=f64, base_step=1000)
+    samples = float(wl.width) * wl.height * spp * steps
+    rl = roofline(wl, args.max_depth, rays, kernel_ms, launches,
+                  workload_key(args.scene, wl.width, wl.height, spp, args.max_depth, args.n, f64), f64=f64)
+    leg = {
+        "dtype": "f64" if f64 else "f32", "entry": "rt_render_f64_device" if f64 else "rt_render_device",
         "workload": f"{args.scene} {wl.width}x{wl.height}, {spp} spp, max depth {args.max_depth}",
-        "steps": args.f64_steps, "warmup": 1, "ms_per_step": 1e3 * secs / args.f64_steps,
+        "steps": steps, "warmup": 1, "ms_per_step": 1e3 * secs / steps,
         "value": rays / secs / 1e6, "unit": "Mrays/s", "msamples_per_s": samples / secs / 1e6,
-        "rays_per_sample": rays / samples,
-        "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tflops / PEAK_FP64_VALU_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms,
-                     "launches": launches, "algorithmic_flops_per_ray": flops_per_ray,
-                     "algorithmic_bytes_per_ray": bytes_per_ray},
-        "note": "walks every path to its end like the reference (no zero-throughput early exit, NaN samples poison the "
-                "pixel): compare with the f32 line in samples/s, not rays/s",
+        "rays_per_sample": rays / samples, "nonfinite_samples_dropped": nonfinite, "roofline": rl,
     }
+    if f64:
+        leg["note"] = ("walks every path to its end like the reference (no zero-throughput early exit, NaN samples poison "
+                       "the pixel): compare with the f32 line in samples/s, not rays/s")
+    else:
+        leg["note"] = ("the f32 product kernel: narrower arithmetic than the reference's f64 (alias.rs:4-7), so this is a peer "
+                       "line, not the metric; it stops zero-throughput paths and drops non-finite samples (rt.h), hence "
+                       "fewer rays per sample: compare with the f64 line in samples/s")
+    return leg
 
 
 OTHER_CONFIGS = [
-    # (tag, scene, width, aspect, n, full spp, bench spp, depth)
-    ("C1", "random_scene", 400, 16.0 / 9.0, 0, 100, 100, 50),
-    ("C3", "final_scene", 1024, 1.0, 0, 10000, 512, 50),
-    ("C4", "bvh_stress", 3840, 16.0 / 9.0, 1000000, 256, 4, 50),
+    # (tag, scene, width, aspect, n, full spp, bench spp, depth, f64 leg: (width, spp) or None)
+    ("C1", "random_scene", 400, 16.0 / 9.0, 0, 100, 100, 50, (400, 100)),
+    ("C3", "final_scene", 1024, 1.0, 0, 10000, 512, 50, (1024, 16)),
+    ("C4", "bvh_stress", 3840, 16.0 / 9.0, 1000000, 256, 4, 50, (640, 1)),
+    # beyond BASELINE.json: the C4 scene grown until its tree (8 M leaves x 64-B nodes = 512 MB + 128 MB of spheres)
+    # no longer fits the 256 MiB Infinity Cache — the configuration in which the walk really streams from HBM
+    ("C4-hbm", "bvh_stress", 1920, 16.0 / 9.0, 8000000, 256, 2, 50, None),
 ]
 
 
-def other_configs(R, torch, device):
+def other_configs(R, torch, device, skip_big=False):
     """BASELINE.json configs C1, C3, C4 on one GPU at bounded spp (the rates are spp-independent once a launch is
-    long enough; C1 is run at its full size)."""
+    long enough; C1 is run at its full size), f32 product walk; `f64` = the same scene on the f64 kernel
+    (reference-order walk: the kernel that follows the oracle path for path) on a bounded sample."""
     lines = []
-    for tag, scene, width, aspect, n, full_spp, spp, depth in OTHER_CONFIGS:
+    for tag, scene, width, aspect, n, full_spp, spp, depth, leg64 in OTHER_CONFIGS:
+        if skip_big and n > 1000000:
+            continue
+        t_build = time.perf_counter()
         wl = Workload(R, torch, scene, width, aspect, n, device)
+        t_build = time.perf_counter() - t_build
         steps = 5 if tag == "C1" else 2
         secs, rays, kernel_ms, launches, nonfinite = time_renders(wl, spp, depth, steps, 1)
-        key = f"{scene} {width}x{wl.height}, {spp} spp, max depth {depth}" + (f", n={n}" if n else "")
+        key = workload_key(scene, width, wl.height, spp, depth, n)
         rl = roofline(wl, depth, rays, kernel_ms, launches, key)
         samples = float(width) * wl.height * spp * steps
-        lines.append({"config": tag, "workload": key, "full_config_spp": full_spp, "steps": steps,
-                      "ms_per_step": 1e3 * secs / steps, "value": rays / secs / 1e6, "unit": "Mrays/s",
-                      "msamples_per_s": samples / secs / 1e6, "rays_per_sample": rays / samples,
-                      "nonfinite_samples_dropped": nonfinite, "dtype": "f32",
-                      "roofline": {k: rl[k] for k in rl if k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "note",
-                                                      "traffic_source",
-                                                      "avg_launch_ms", "algorithmic_flops_per_ray",
-                                                      "algorithmic_bytes_per_ray", "frac_valu_fp32", "frac_hbm",
-                                                      "scene_bytes")}})
+        line = {"config": tag, "workload": key, "full_config_spp": full_spp, "steps": steps,
+                "ms_per_step": 1e3 * secs / steps, "value": rays / secs / 1e6, "unit": "Mrays/s",
+                "msamples_per_s": samples / secs / 1e6, "rays_per_sample": rays / samples,
+                "nonfinite_samples_dropped": nonfinite, "dtype": "f32", "scene_build_s": t_build,
+                "roofline": {k: rl[k] for k in rl if k not in ("traffic_note", "algorithmic_work_counted_on", "launches")}}
         del wl
         torch.cuda.empty_cache()
+        if leg64:
+            w64, spp64 = leg64
+            wl = Workload(R, torch, scene, w64, aspect, n, device)
+            secs, rays, kernel_ms, launches, _ = time_renders(wl, spp64, depth, 1, 1, f64=True)
+            s64 = float(w64) * wl.height * spp64
+            line["f64"] = {"workload": workload_key(scene, w64, wl.height, spp64, depth, n, True), "ms_per_step": 1e3 * secs,
+                           "value": rays / secs / 1e6, "unit": "Mrays/s", "msamples_per_s": s64 / secs / 1e6,
+                           "rays_per_sample": rays / s64, "kernel": "render_persist_kernel<double, ..., TRAV_REFERENCE>"}
+            del wl
+            torch.cuda.empty_cache()
+        lines.append(line)
     return lines
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=4096, help="samples per pixel PER GPU per step")
+    ap.add_argument("--precision", choices=("f64", "f32"), default="f64",
+                    help="arithmetic of the timed kernel; f64 = the reference's (alias.rs:4-7)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --spp per GPU per step; strong: --spp per step, split over the GPUs by shard_samples")
+    ap.add_argument("--config", choices=("C2", "C5"), default="C2",
+                    help="C2 = Cornell 1024^2 x 4096 spp (the metric's); C5 = Cornell 3840x2160 x 65536 spp, strong scaling")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel per step (per GPU when --scaling weak)")
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--spp-per-launch", type=int, default=0)
     ap.add_argument("--scene", default="cornell_box")
-    ap.add_argument("--aspect", type=float, default=1.0)
+    ap.add_argument("--aspect", type=float, default=None)
     ap.add_argument("--n", type=int, default=0, help="scene 7 (bvh_stress): number of spheres")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of the CPU baseline sample")
-    ap.add_argument("--no-f64-leg", action="store_true")
-    ap.add_argument("--f64-spp", type=int, default=256, help="samples per pixel of the f64 leg's step")
-    ap.add_argument("--f64-steps", type=int, default=2)
+    ap.add_argument("--no-peer-leg", action="store_true", help="skip the other precision's line")
+    ap.add_argument("--leg-steps", type=int, default=3)
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-big-scene", action="store_true", help="other_configs without the 8 M-sphere scene (15 s of host build)")
     args = ap.parse_args()
+    if args.config == "C5":
+        args.width = args.width or 3840
+        args.aspect = args.aspect or 16.0 / 9.0
+        args.spp = args.spp or 65536
+        args.scaling = "strong"
+    args.width = args.width or 1024
+    args.aspect = args.aspect or 1.0
+    args.spp = args.spp or 4096
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)  # nothing above has touched a GPU (torch is not even imported yet)
@@ -286,7 +361,7 @@ def main():
     import torch.distributed as dist
 
     import raytracer_amd as R
-    from raytracer_amd.distributed import allreduce_accum
+    from raytracer_amd.distributed import allreduce_accum, shard_samples
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -314,24 +389,31 @@ def main():
             # does not time it
             dist.all_reduce(torch.zeros(1, device=torch.device("cuda", local_rank)))
 
+    f64 = args.precision == "f64"
+    strong = args.scaling == "strong"
     wl = Workload(R, torch, args.scene, args.width, args.aspect, args.n, local_rank)
     width, height = wl.width, wl.height
     dev = torch.device("cuda", local_rank)
+    accum = wl.accum_for(f64)
     from raytracer_amd import _ffi as F
+    tonemap = F.hip.rt_tonemap_f64_device if f64 else F.hip.rt_tonemap_device
+    spp_image = args.spp if strong else args.spp * world  # samples per pixel of the merged image of one step
 
     def step(i):
         # every step renders fresh global sample indices, so no step can reuse another's result
-        offset = (i * world + rank) * args.spp
-        st = wl.ds.render_device(wl.accum.data_ptr(), width, height, args.spp, args.max_depth, seed=1,
-                                 sample_offset=offset, spp_per_launch=args.spp_per_launch, stream=wl.stream)
-        if rehearsal and distributed:  # gloo reduces host tensors
-            host = wl.accum.cpu()
-            allreduce_accum(host)
-            wl.accum.copy_(host)
+        if strong:   # this rank's contiguous share of the step's samples (the rule of rt_multi_shard)
+            offset, count = shard_samples(args.spp, rank, world, base_offset=i * args.spp)
         else:
-            allreduce_accum(wl.accum)
-        F.check_hip(F.hip.rt_tonemap_device(local_rank, wl.accum.data_ptr(), width * height, args.spp * world,
-                                            wl.rgb8.data_ptr(), wl.stream))
+            offset, count = (i * world + rank) * args.spp, args.spp
+        st = wl.ds.render_device(accum.data_ptr(), width, height, count, args.max_depth, seed=1,
+                                 sample_offset=offset, spp_per_launch=args.spp_per_launch, stream=wl.stream, f64=f64)
+        if rehearsal and distributed:  # gloo reduces host tensors
+            host = accum.cpu()
+            allreduce_accum(host)
+            accum.copy_(host)
+        else:
+            allreduce_accum(accum)
+        F.check_hip(tonemap(local_rank, accum.data_ptr(), width * height, spp_image, wl.rgb8.data_ptr(), wl.stream))
         return st
 
     def sync():
@@ -367,8 +449,9 @@ def main():
         total_rays = float(rays)
 
     if rank == 0:
-        samples = float(width) * height * args.spp * world * args.steps
-        workload = (f"{args.scene} {width}x{height}, {args.spp} spp per GPU, max depth {args.max_depth}"
+        samples = float(width) * height * spp_image * args.steps
+        per = "per step, split over the GPUs" if strong else "per GPU"
+        workload = (f"{args.scene} {width}x{height}, {args.spp} spp {per}, max depth {args.max_depth}"
                     + (f", n={args.n}" if args.n else ""))
         out = {
             "metric": METRIC,
@@ -379,32 +462,43 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.precision,
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
             "config": {"workload": workload, "scene_seed": 5, "bvh_seed": 7, "render_seed": 1,
-                       "parallelism": f"sample-sharded x{world}, RCCL sum all-reduce of the accumulator"},
+                       "entry": "rt_render_f64_device" if f64 else "rt_render_device",
+                       "parallelism": f"sample-sharded x{world} ({args.scaling} scaling), RCCL sum all-reduce of the "
+                                      f"{args.precision} accumulator"},
             "msamples_per_s": samples / elapsed / 1e6,
             "rays_per_sample": total_rays / samples,
-            "nonfinite_samples_dropped": nonfinite,
+            "nonfinite_samples": nonfinite,
         }
+        if f64:
+            out["note"] = ("the reference's own arithmetic (f64, alias.rs:4-7); the kernel walks every path to its end like the "
+                           "reference (5.1 rays per sample in this scene) and follows the CPU oracle path for path "
+                           "(tests/test_gpu_parity.py); the f32 product kernel is the f32_leg line")
         # roofline of the dominant kernel: live HIP-event duration on the launch stream (rt_stats.kernel_ms, events
-        # recorded on the stream the kernels are launched on), algorithmic work from a counted pass
-        key = (f"{args.scene} {width}x{height}, {args.spp} spp, max depth {args.max_depth}" + (f", n={args.n}" if args.n else ""))
-        out["roofline"] = roofline(wl, args.max_depth, rays, kernel_ms, launches, key)
-        if world == 1 and not args.no_f64_leg:
-            out["f64_leg"] = f64_leg(wl, args)
+        # recorded on the stream the kernels are launched on), algorithmic work from a counted pass.  (Rank 0's own
+        # launches: with strong scaling a launch renders this rank's share of the samples.)
+        spp_launch = shard_samples(args.spp, 0, world)[1] if strong else args.spp
+        key = workload_key(args.scene, width, height, spp_launch, args.max_depth, args.n, f64)
+        out["roofline"] = roofline(wl, args.max_depth, rays, kernel_ms, launches, key, f64=f64)
+        if world == 1 and not args.no_peer_leg:
+            out["f32_leg" if f64 else "f64_leg"] = peer_leg(wl, args, not f64)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args, width, height)
             out["cpu_baseline"] = cb
-            # like for like: the f32 kernel stops zero-throughput paths (fewer rays per sample than the oracle,
-            # which walks them like the reference), so the honest ratio is in SAMPLES per second
+            # like for like: the oracle walks every path to its end like the reference and like the f64 kernel; the
+            # f32 kernel stops zero-throughput paths (fewer rays per sample), so compare in SAMPLES per second
             out["gpu_vs_cpu_msamples"] = out["msamples_per_s"] / cb["msamples_per_s"]
-            if "f64_leg" in out:
-                out["f64_leg"]["gpu_vs_cpu_msamples"] = out["f64_leg"]["msamples_per_s"] / cb["msamples_per_s"]
+            for leg in ("f32_leg", "f64_leg"):
+                if leg in out:
+                    out[leg]["gpu_vs_cpu_msamples"] = out[leg]["msamples_per_s"] / cb["msamples_per_s"]
         if world == 1 and not args.no_other_configs:
-            out["other_configs"] = other_configs(R, torch, local_rank)
+            del wl
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(R, torch, local_rank, skip_big=args.no_big_scene)
         print(json.dumps(out), flush=True)
 
     if distributed:

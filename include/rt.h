@@ -335,6 +335,13 @@ void rt_tonemap(const float* accum_rgb, uint64_t n_pixels, uint64_t spp, uint8_t
 int rt_tonemap_device(int device, const float* accum_rgb_device, uint64_t n_pixels, uint64_t spp,
                       uint8_t* rgb8_device, void* stream);
 
+/* The same in the reference's own arithmetic, for the f64 accumulators of rt_render_f64 / rt_render_f64_device:
+ * `pixel_color /= spp` and pixel_from_color in f64 (main.rs:167-168, 51-63), quantised exactly as the reference
+ * quantises its f64 pixel.                                                                   */
+void rt_tonemap_f64(const double* accum_rgb, uint64_t n_pixels, uint64_t spp, uint8_t* rgb8);
+int rt_tonemap_f64_device(int device, const double* accum_rgb_device, uint64_t n_pixels, uint64_t spp,
+                          uint8_t* rgb8_device, void* stream);
+
 /* Device-side evaluation of the two functions the reference's own tests pin
  * (hittable.rs:547-556 get_sphere_uv; alias.rs:188-215 quaternion rotate), so the KATs can
  * be run against the kernels' code, not only against the oracle.  n items each.          */

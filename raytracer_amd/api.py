@@ -269,9 +269,15 @@ def render_multi(host_scene, devices, width, height, spp, max_depth, seed=1, sam
 
 
 def tonemap(accum, spp):
-    """main.rs:167-168 + 51-63: mean, gamma 2, clamp, quantise."""
-    accum = np.ascontiguousarray(accum, dtype=np.float32)
+    """main.rs:167-168 + 51-63: mean, gamma 2, clamp, quantise.  A float64 accumulator (rt_render_f64) is divided and
+    quantised in f64 like the reference's own pixel (rt_tonemap_f64); anything else goes through the f32 form."""
+    accum = np.asarray(accum)
     out = np.zeros(accum.shape, dtype=np.uint8)
+    if accum.dtype == np.float64:
+        accum = np.ascontiguousarray(accum)
+        F.hip.rt_tonemap_f64(_ptr(accum), accum.size // 3, spp, _ptr(out))
+        return out
+    accum = np.ascontiguousarray(accum, dtype=np.float32)
     F.hip.rt_tonemap(_ptr(accum), accum.size // 3, spp, _ptr(out))
     return out
 

@@ -1914,6 +1914,22 @@ __global__ void __launch_bounds__(BLOCK) primary_fix_kernel(SceneView<double> sc
   }
   if (front_face) front_face[pixel] = h.front_face ? 1 : 0;
 }
+
+// main.rs:167-168, 51-63 in the reference's own arithmetic: the f64 SUM divided by spp, gamma 2, clamp, x256, truncate
+// (NaN -> 0 like Rust's saturating `as u8`)
+__global__ void tonemap_f64_kernel(const double* __restrict__ accum, uint64_t n, double spp, uint8_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    double g = sqrt(accum[i] / spp);
+    uint8_t q = 0;
+    if (g == g) {
+      g = g < 0.0 ? 0.0 : (g > 0.9999 ? 0.9999 : g);
+      q = (uint8_t)(g * 256.0);
+    }
+    out[i] = q;
+  }
+}
 #endif  // RT_DEFINE_F64_FIX
 
 #ifdef RT_DEFINE_COMMON

@@ -236,13 +236,8 @@ int rth_render(const rth_render_opts* o, uint8_t* rgb8, float* accum, uint32_t* 
     if (rc != RT_OK) {
       g_err = std::string("rth_render: ") + rt_last_error();
     } else {
-      for (size_t i = 0; i < acc64.size(); ++i) {
-        acc[i] = (float)acc64[i];
-        const double g = std::sqrt(acc64[i] / (double)p.spp);
-        uint8_t q = 0;  // (NaN as u8 = 0)
-        if (g == g) q = (uint8_t)((g < 0.0 ? 0.0 : (g > 0.9999 ? 0.9999 : g)) * 256.0);
-        rgb8[i] = q;
-      }
+      for (size_t i = 0; i < acc64.size(); ++i) acc[i] = (float)acc64[i];
+      rt_tonemap_f64(acc64.data(), (uint64_t)w * h, p.spp, rgb8);
     }
     rth_scene_free(hs);
     return rc;

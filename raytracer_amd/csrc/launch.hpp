@@ -58,6 +58,7 @@ hipError_t launch_wf_iteration(const SceneView<float>& sc, const CameraView<floa
                                uint32_t trace_blocks, hipStream_t st);
 hipError_t wf_trace_blocks_per_cu(size_t lds_bytes, int* out);
 hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t* out, hipStream_t st);
+hipError_t launch_tonemap_f64(const double* accum, uint64_t n, double spp, uint8_t* out, hipStream_t st);
 hipError_t launch_zero(void* dst, size_t bytes, hipStream_t st);
 hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, uint32_t n_src, hipStream_t st);
 hipError_t launch_kat_libm(uint32_t n, uint32_t op, const double* a, const double* b, double* out, hipStream_t st);

@@ -25,7 +25,7 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
                                              uint32_t n_samples, uint32_t max_depth, uint64_t seed, int accumulate,
                                              bool stats, RT_REAL* accum, DeviceStats* dstats, LaunchShape shape,
                                              hipStream_t st) {
-  RenderArgs a;
+  RenderArgs a{};
   a.width = width;
   a.height = height;
   a.sample_begin = sample_begin;
@@ -42,6 +42,10 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   a.wave_tiles_x = shape.wave_tiles_x;
   a.wave_tiles = shape.wave_tiles;
   a.total_units = shape.total_units;
+  a.leaf_shift = shape.leaf_shift;
+  a.direct_accum = shape.direct_accum;
+  a.xcd_chunk = shape.xcd_chunk;
+  a.tile_band = shape.tile_band;
 #if RT_HAS_LINEAR
   if (shape.trav == TRAV_LINEAR && shape.unit_samples > 0) {  // persistent form: grid = workers, not tiles
     if (stats)
@@ -211,6 +215,13 @@ hipError_t wf_trace_blocks_per_cu(size_t lds_bytes, int* out) {
 }
 #endif
 #ifdef RT_DEFINE_F64_FIX
+hipError_t launch_tonemap_f64(const double* accum, uint64_t n, double spp, uint8_t* out, hipStream_t st) {
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) blocks = 1;
+  RT_LAUNCH(tonemap_f64_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, accum, n, spp, out);
+  return hipGetLastError();
+}
 hipError_t launch_primary_fix_f64(const SceneView<double>& sc, const CameraView<double>& cam, uint32_t width, uint32_t height,
                                   uint64_t seed, double time, const uint8_t* unsure, uint32_t* prim_id, float* t, float* normal,
                                   float* uv, uint8_t* front_face, uint32_t ref_stack_depth, hipStream_t st) {

@@ -1627,6 +1627,26 @@ int rt_tonemap_device(int device, const float* d_accum, uint64_t n_pixels, uint6
   return RT_OK;
 }
 
+void rt_tonemap_f64(const double* accum, uint64_t n_pixels, uint64_t spp, uint8_t* rgb8) {
+  if (!accum || !rgb8) return;
+  for (uint64_t i = 0; i < 3 * n_pixels; ++i) {
+    double g = std::sqrt(accum[i] / (double)spp);
+    uint8_t q = 0;
+    if (g == g) {
+      g = g < 0.0 ? 0.0 : (g > 0.9999 ? 0.9999 : g);
+      q = (uint8_t)(g * 256.0);
+    }
+    rgb8[i] = q;
+  }
+}
+
+int rt_tonemap_f64_device(int device, const double* d_accum, uint64_t n_pixels, uint64_t spp, uint8_t* d_rgb8, void* stream) {
+  if (!d_accum || !d_rgb8) return fail(RT_ERR_BAD_ARG, "rt_tonemap_f64_device: null argument");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(launch_tonemap_f64(d_accum, 3 * n_pixels, (double)spp, d_rgb8, (hipStream_t)stream));
+  return RT_OK;
+}
+
 static int kat_common(int device, size_t in_bytes[], const void* in[], int n_in, size_t out_bytes, void* out,
                       hipError_t (*run)(void** d_in, void* d_out, void* ctx), void* ctx) {
   HIP_TRY(hipSetDevice(device));

@@ -173,6 +173,21 @@ def test_tonemap_matches_reference_formula():
     assert list(got.reshape(-1)[7:10]) == [0, 0, 255]
 
 
+def test_tonemap_f64_is_the_references_own_arithmetic():
+    """rt_tonemap_f64: `pixel_color /= spp` then pixel_from_color, all in f64 (main.rs:167-168, 51-63) — byte for byte
+    the oracle's, also where f32 rounding of the sum would cross a quantisation step."""
+    import raytracer_amd as R
+    import oracle_ffi as O
+    rng = np.random.default_rng(3)
+    spp = 4096
+    steps = (np.arange(1, 256) / 256.0) ** 2 * spp  # sums whose mean sits exactly on a quantisation step
+    vals = np.concatenate([steps, np.nextafter(steps, 0), np.nextafter(steps, np.inf), rng.random(765) * spp * 1.2,
+                           [0.0, -1.0, np.nan, np.inf, -np.inf, 1e-300]])
+    acc = np.resize(vals, (len(vals) + 2) // 3 * 3).reshape(-1, 1, 3).astype(np.float64)
+    got = R.tonemap(acc, spp)
+    assert got.dtype == np.uint8 and np.array_equal(got, O.tonemap(acc, spp))
+
+
 def test_no_gpu_means_an_error_not_a_cpu_fallback():
     """The product path has no CPU fallback: on a machine without a GPU (the build container) a valid scene
     is refused with RT_ERR_HIP and a message, and the command line exits 1.  Skipped where a GPU exists."""

@@ -71,6 +71,26 @@ def test_render_device_accumulates_and_tonemaps_like_the_host():
     assert np.array_equal(rgb.cpu().numpy(), R.tonemap(acc.cpu().numpy(), 16))
 
 
+def test_f64_accumulator_tonemaps_on_the_device_like_the_oracle():
+    """rt_tonemap_f64_device on the f64 kernel's accumulator == the oracle's image of the same render, byte for byte
+    (main.rs:167-168, 51-63 in f64)."""
+    import torch
+    import oracle_ffi as O
+    import raytracer_amd as R
+    from raytracer_amd import _ffi as F
+    ds = R.DeviceScene(R.HostScene(6, 1.0), 0)
+    w = h = 48
+    acc = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    ds.render_device(acc.data_ptr(), w, h, 16, 8, seed=3, f64=True)
+    rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    F.check_hip(F.hip.rt_tonemap_f64_device(0, acc.data_ptr(), w * h, 16, rgb.data_ptr(), None))
+    torch.cuda.synchronize()
+    host = acc.cpu().numpy()
+    assert np.array_equal(rgb.cpu().numpy(), R.tonemap(host, 16))
+    o, _, _ = O.OracleScene(6, 1.0).render(w, h, 16, 8, seed=3)
+    assert (rgb.cpu().numpy() != O.tonemap(o, 16)).mean() <= 1e-3  # (a sum 1e-16 apart may straddle a step)
+
+
 def test_arguments_are_validated_not_trusted():
     """The reference panics (cam.rs:69 empty shutter range) or divides by zero (main.rs:161-163, w-1);
     the library returns an error code and a message instead."""

@@ -9,4 +9,4 @@ timeout -k 10 120 python3 tools/f64_ab.py 256 || exit $?
 for u in ${UNITS:-16 32 64 128 256}; do
   echo -n "4096 spp, unit $u: "; RT_UNIT_SAMPLES=$u timeout -k 10 200 python3 tools/f64_ab.py 4096 || exit $?
 done
-echo -n "f32 headline: "; timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-f64-leg --no-other-configs --steps 3 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['value'],1),'Mrays/s', round(d['ms_per_step'],1),'ms/step')"
+echo -n "f32 headline: "; timeout -k 10 200 python3 bench.py --precision f32 --no-cpu-baseline --no-peer-leg --no-other-configs --steps 3 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['value'],1),'Mrays/s', round(d['ms_per_step'],1),'ms/step')"

@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 tag=$1; key=$2; shift 2
 out=$PWD/gpurun_out/traffic/$tag; rm -rf $out; mkdir -p $out
-B="$PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f64-leg --no-other-configs $*"
+B="$PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-peer-leg --no-other-configs $*"
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o pmc -- python3 $B > $out/fetch.log 2>&1 || { tail -3 $out/fetch.log; exit 1; }
 timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o pmc -- python3 $B > $out/write.log 2>&1 || { tail -3 $out/write.log; exit 1; }
 timeout -s KILL 150 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/l2 -o pmc -- python3 $B > $out/l2.log 2>&1 || { tail -3 $out/l2.log; exit 1; }

@@ -7,7 +7,7 @@ tag=${1:-r01}; shift
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-BENCH="$PWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f64-leg --no-other-configs $*"
+BENCH="$PWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-peer-leg --no-other-configs $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 $BENCH > $out/trace.log 2>&1 || { echo "trace failed"; tail -5 $out/trace.log; exit 1; }
 # PMC passes on a short run (counters are per-dispatch; rates per ray are spp-independent)
 SHORT="$PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp 256 $*"
