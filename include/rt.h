@@ -28,6 +28,7 @@ extern "C" {
 #define RT_ABI_VERSION 2u  /* 2: rt_scene_desc.light_box, RT_LIGHT_CUBE, RT_MAT_AREA_LIGHT */
 #define RT_MAX_BVH_HEIGHT 63u       /* nodes on a root-to-leaf path: 4 B per level and lane of LDS, 64 KiB per workgroup */
 #define RT_NOALLOC_MAX_LAUNCHES 63u /* rt_render_device_noalloc: kernel launches per call (256 B of static scratch each) */
+#define RT_NOALLOC_PARTITIONS 4u    /* ... and how many scenes of one GPU have a partition of that scratch to themselves */
 
 typedef struct rt_scene rt_scene; /* opaque: one per (scene, device) */
 
@@ -184,8 +185,11 @@ typedef struct rt_camera {
 #define RT_FLAG_WAVEFRONT 4u  /* f32, BVH-bound scenes only (ignored elsewhere): render with the wavefront form — a pool of
                                  paths in HBM, a TRACE and a SHADE kernel per bounce (device/wavefront.hpp) — instead of the
                                  megakernel.  Same paths, same draws, same image up to f32 summation order.  Measured SLOWER
-                                 (DESIGN.md 3.3): kept as the evidence for the megakernel-versus-queue question.  The call
-                                 allocates the pool on first use (72 B per slot, 2^21 slots) and synchronises the stream. */
+                                 (DESIGN.md 3.3): kept as the evidence for the megakernel-versus-queue question.  With this
+                                 flag (or RT_WAVEFRONT=1 in the environment) rt_render_device is NOT asynchronous and NOT
+                                 allocation-free: the call allocates the pool on first use (72 B per slot, 2^21 slots; plus
+                                 a pinned word) and synchronises the stream every few bounces.  Ignored (megakernel) when
+                                 an eighth-by-eighth-pixel tile count x spp reaches 2^32 (32-bit job cursors).          */
 
 typedef struct rt_params {
   uint32_t width, height;   /* image size; h = trunc(w / aspect) is the caller's job (main.rs:112) */
@@ -262,11 +266,11 @@ int rt_render_f64(rt_scene* scene, const rt_camera* cam, const rt_params* params
  * added to the buffer's contents, else the buffer is overwritten.  If stats is non-null the
  * call synchronises the stream before returning.  This is what the multi-GPU path uses:
  * each rank renders its sample range, then one RCCL sum all-reduce merges the buffers.
- * ONE STREAM AT A TIME PER SCENE: every call on an rt_scene shares that scene's counter block (work
- * counters, the persistent kernels' unit counter) and its two timing events, so a call may only be
- * enqueued once the previous call on the same scene has been enqueued on the SAME stream, or has
- * completed; calls on different streams that overlap on one scene race (skipped or doubled sample
- * units).  Use one rt_scene per stream.
+ * STREAMS AND THREADS: a call takes a counter block of its own (work counters, the persistent kernels' unit
+ * counter: the next of 16 chunks the scene holds) and, with stats, its own pair of timing events, so calls on
+ * ONE scene may be enqueued on different streams, also from different threads, and overlap on the GPU.  A
+ * chunk comes round again after 16 further calls on that scene: do not keep more than 16 calls of one scene
+ * in flight.  (RT_FLAG_WAVEFRONT calls share the scene's path pool: one at a time.)
  * NON-FINITE SAMPLES (f32 entries: rt_render, rt_render_device, rt_render_multi): a sample whose radiance
  * is NaN or infinite is dropped and counted in rt_stats.nonfinite_samples, the divisor stays spp; the
  * reference adds it to the pixel (main.rs:165), which then quantises to 0 (main.rs:59-61, Q9/Q10 of
@@ -283,12 +287,15 @@ int rt_render_f64_device(rt_scene* scene, const rt_camera* cam, const rt_params*
  * tight serving loops, harnesses that forbid hipMalloc.  Same contract and same kernels as
  * rt_render_device, but the kernels' scratch (per launch: the work counters and the persistent
  * kernels' unit counter) lives in a file-scope __device__ array of RT_NOALLOC_MAX_LAUNCHES x 256 B =
- * 15.75 KiB that every GPU the library runs on holds until the process ends; the call itself makes no
+ * 15.75 KiB per partition, RT_NOALLOC_PARTITIONS partitions = 63 KiB that every GPU the library runs on holds
+ * until the process ends; the call itself makes no
  * hipMalloc / hipFree or other allocating call (memsets, launches, two event records; with stats != NULL
  * also one stream synchronise and a <= 16 KiB copy-back, so pass NULL under capture).  A call that needs
  * more than RT_NOALLOC_MAX_LAUNCHES launches (spp / spp_per_launch, default 4096 per launch) is refused
- * with RT_ERR_BAD_ARG.  Every call on one GPU shares that GPU's array (whatever the scene): calls that
- * overlap on one GPU race; the call zeroes what it uses.                                          */
+ * with RT_ERR_BAD_ARG.  A scene uses the partition that its creation order on its GPU selects (ordinal modulo
+ * RT_NOALLOC_PARTITIONS): calls through this entry on ONE scene, or on two scenes of one GPU that share a
+ * partition (every fifth scene created there), must not overlap — they would race on the unit counters;
+ * calls on scenes with different partitions may.  The call zeroes what it uses.                     */
 int rt_render_device_noalloc(rt_scene* scene, const rt_camera* cam, const rt_params* params,
                              float* accum_rgb_device, int accumulate, void* stream, rt_stats* stats);
 

@@ -419,7 +419,12 @@ RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng
     else
       h = prim_t(sc, cur, r, inv_d, a, t_min, closest, t, cnt);
     // hittable.rs:405-411: the first record found is kept whatever its t (a NaN t from a NaN ray included — the
-    // reference returns it, and every later `right.t < left.t` is then false); a later one must be strictly closer
+    // reference returns it, and every later `right.t < left.t` is then false); a later one must be strictly closer.
+    // KNOWN GAP (NaN t only, never seen in any sweep): in the recursion a NaN-t record that is the first one found
+    // inside a RIGHT subtree becomes that subtree's t_max, so the rest of that subtree is discarded, and the
+    // subtree's answer (NaN) then loses against the left record; here `closest` stays finite across that subtree, so
+    // a later leaf of it with t < closest is still accepted.  The two agree whenever the NaN record is the walk's
+    // first record (handled above) or no NaN t arises at all (every finite ray against finite geometry).
     if (h && (best == REF_NONE || t < closest)) {
       closest = t;
       best = cur;

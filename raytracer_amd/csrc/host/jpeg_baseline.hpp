@@ -47,6 +47,7 @@ class Decoder {
       switch (m) {
         case 0xC0:
         case 0xC1:
+          if (have_frame) fail("a second SOF segment (hierarchical / multi-frame JPEG is not supported)");
           read_frame();
           have_frame = true;
           break;
@@ -118,6 +119,7 @@ class Decoder {
       const int pq = d_[p] >> 4, tq = d_[p] & 15;
       ++p;
       if (tq > 3 || pq > 1 || p + (pq ? 128 : 64) > end) fail("bad DQT segment");
+      if (pq == 1) fail("16-bit quantisation tables are not supported (8-bit baseline JPEG only)");
       for (int i = 0; i < 64; ++i) {  // stored in zig-zag order; kept that way (the coefficients arrive in it too)
         q_[tq][i] = pq ? (uint16_t)((d_[p] << 8) | d_[p + 1]) : d_[p];
         p += pq ? 2 : 1;
@@ -169,6 +171,7 @@ class Decoder {
     if (nc != 1 && nc != 3) fail("only grey and YCbCr JPEG is supported (" + std::to_string(nc) + " components)");
     if (len != (size_t)(8 + 3 * nc)) fail("bad SOF segment");
     comp_.assign(nc, Component());
+    hmax_ = vmax_ = 1;
     for (int i = 0; i < nc; ++i) {
       Component& c = comp_[i];
       c.id = s[6 + 3 * i];
@@ -228,7 +231,7 @@ class Decoder {
   }
   static int extend(int v, int t) { return t == 0 ? 0 : (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v); }  // Figure F.12
 
-  static uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+  static uint8_t clamp8(int64_t x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 
   // 8x8 inverse DCT, Loeffler-Ligtenberg-Moschytz, 12-bit fixed-point constants; columns first (to 10 fractional
   // bits dropped), then rows with the +128 level shift and the final rounding folded into one add.
@@ -237,24 +240,25 @@ class Decoder {
     constexpr int32_t c0_541 = fx(0.5411961), c1_847 = fx(1.847759065), c0_765 = fx(0.765366865), c1_175 = fx(1.175875602),
                       c0_298 = fx(0.298631336), c2_053 = fx(2.053119869), c3_072 = fx(3.072711026), c1_501 = fx(1.501321110),
                       c0_899 = fx(0.899976223), c2_562 = fx(2.562915447), c1_961 = fx(1.961570560), c0_390 = fx(0.390180644);
-    int32_t tmp[64];
-    auto pass = [&](int32_t s0, int32_t s1, int32_t s2, int32_t s3, int32_t s4, int32_t s5, int32_t s6, int32_t s7, int32_t bias,
-                    int32_t* e /* x0 x1 x2 x3 */, int32_t* o /* t0 t1 t2 t3 */) {
-      int32_t p1 = (s2 + s6) * c0_541;
-      const int32_t t2 = p1 - s6 * c1_847, t3 = p1 + s2 * c0_765;
-      const int32_t t0 = (s0 + s4) * 4096, t1 = (s0 - s4) * 4096;
+    int64_t tmp[64];  // (64-bit intermediates: a corrupt stream may carry coefficients far outside what an encoder
+                      // produces, and the products below must not overflow — same values as 32-bit arithmetic on a valid file)
+    auto pass = [&](int64_t s0, int64_t s1, int64_t s2, int64_t s3, int64_t s4, int64_t s5, int64_t s6, int64_t s7, int64_t bias,
+                    int64_t* e /* x0 x1 x2 x3 */, int64_t* o /* t0 t1 t2 t3 */) {
+      int64_t p1 = (s2 + s6) * c0_541;
+      const int64_t t2 = p1 - s6 * c1_847, t3 = p1 + s2 * c0_765;
+      const int64_t t0 = (s0 + s4) * 4096, t1 = (s0 - s4) * 4096;
       e[0] = t0 + t3 + bias;
       e[3] = t0 - t3 + bias;
       e[1] = t1 + t2 + bias;
       e[2] = t1 - t2 + bias;
-      int32_t q0 = s7, q1 = s5, q2 = s3, q3 = s1;
-      const int32_t p3 = q0 + q2, p4 = q1 + q3, p1b = q0 + q3, p2b = q1 + q2;
-      const int32_t p5 = (p3 + p4) * c1_175;
+      int64_t q0 = s7, q1 = s5, q2 = s3, q3 = s1;
+      const int64_t p3 = q0 + q2, p4 = q1 + q3, p1b = q0 + q3, p2b = q1 + q2;
+      const int64_t p5 = (p3 + p4) * c1_175;
       q0 *= c0_298;
       q1 *= c2_053;
       q2 *= c3_072;
       q3 *= c1_501;
-      const int32_t r1 = p5 - p1b * c0_899, r2 = p5 - p2b * c2_562, r3 = -p3 * c1_961, r4 = -p4 * c0_390;
+      const int64_t r1 = p5 - p1b * c0_899, r2 = p5 - p2b * c2_562, r3 = -p3 * c1_961, r4 = -p4 * c0_390;
       o[3] = q3 + r1 + r4;
       o[2] = q2 + r2 + r3;
       o[1] = q1 + r2 + r4;
@@ -262,13 +266,13 @@ class Decoder {
     };
     for (int c = 0; c < 8; ++c) {
       const int32_t* s = in + c;
-      int32_t* t = tmp + c;
+      int64_t* t = tmp + c;
       if (!(s[8] | s[16] | s[24] | s[32] | s[40] | s[48] | s[56])) {  // a constant column
-        const int32_t dc = s[0] * 4;
+        const int64_t dc = (int64_t)s[0] * 4;
         for (int r = 0; r < 8; ++r) t[8 * r] = dc;
         continue;
       }
-      int32_t e[4], o[4];
+      int64_t e[4], o[4];
       pass(s[0], s[8], s[16], s[24], s[32], s[40], s[48], s[56], 512, e, o);
       t[0] = (e[0] + o[3]) >> 10;
       t[56] = (e[0] - o[3]) >> 10;
@@ -280,9 +284,9 @@ class Decoder {
       t[32] = (e[3] - o[0]) >> 10;
     }
     for (int r = 0; r < 8; ++r) {
-      const int32_t* t = tmp + 8 * r;
+      const int64_t* t = tmp + 8 * r;
       uint8_t* q = out + (size_t)r * out_stride;
-      int32_t e[4], o[4];
+      int64_t e[4], o[4];
       pass(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], 65536 + (128 << 17), e, o);
       q[0] = clamp8((e[0] + o[3]) >> 17);
       q[7] = clamp8((e[0] - o[3]) >> 17);
@@ -305,6 +309,9 @@ class Decoder {
     const int t = decode_symbol(dc_[c.td]);
     if (t > 11) fail("corrupt entropy-coded data (DC category)");
     c.pred += extend(get_bits(t), t);
+    // a conforming stream keeps the predictor inside 16 bits (T.81 F.1.2.1); a corrupt DC run must not be able to
+    // overflow the int32 products below and in the inverse DCT
+    if (c.pred < -32768 || c.pred > 32767) fail("corrupt entropy-coded data (DC predictor out of range)");
     coef[0] = c.pred * q[0];
     for (int k = 1; k < 64;) {  // T.81 Figure F.13
       const int rs = decode_symbol(ac_[c.ta]);
@@ -316,7 +323,7 @@ class Decoder {
       }
       k += r;
       if (k > 63) fail("corrupt entropy-coded data (run past the block)");
-      coef[zigzag[k]] = extend(get_bits(s), s) * q[k];
+      coef[zigzag[k]] = extend(get_bits(s), s) * q[k];  // |.| <= 32767 * 255: fits; the inverse DCT works in 64 bits
       ++k;
     }
     idct(coef, out, c.stride);
@@ -324,6 +331,7 @@ class Decoder {
 
   void read_scan() {
     const size_t len = segment_length();
+    if (len < 3) fail("bad SOS segment");  // (before its first byte is read: a length-2 SOS may end the file)
     const uint8_t* s = d_ + pos_ + 2;
     const int ns = s[0];
     if (ns != (int)comp_.size() || len != (size_t)(6 + 2 * ns))

@@ -3,6 +3,7 @@
 // by rt_f32.hip / rt_f64.hip.
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -589,14 +590,18 @@ constexpr uint32_t TARGET_WAVES = 96u * 1024u;
 // never pass the array's NAME to a kernel or a memset: it is a host-side stand-in, not a device address.
 constexpr size_t NOALLOC_SLOT_BYTES = 256;
 static_assert(sizeof(DeviceStats) <= NOALLOC_SLOT_BYTES, "one DeviceStats block per scratch slot");
-static __device__ __align__(256) unsigned char scratch[NOALLOC_SLOT_BYTES * RT_NOALLOC_MAX_LAUNCHES];
+// RT_NOALLOC_PARTITIONS partitions of RT_NOALLOC_MAX_LAUNCHES slots: an rt_scene uses the partition its creation
+// ordinal on that device selects, so that up to that many scenes (streams, threads) may use the entry side by side.
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SLOT_BYTES * RT_NOALLOC_MAX_LAUNCHES * RT_NOALLOC_PARTITIONS];
 
 namespace {
 constexpr int MAX_DEVICES = 64;
 std::mutex g_scratch_mutex;
 unsigned char* g_scratch_ptr[MAX_DEVICES] = {};
+uint32_t g_scene_ordinal[MAX_DEVICES] = {};  // scenes created so far per device (under g_scratch_mutex)
 
 // Device address of `scratch` on `device` (which must be the current device).
+// *out: the partition of the next scene created on this device.
 hipError_t noalloc_scratch_for(int device, unsigned char** out) {
   *out = nullptr;
   if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
@@ -608,7 +613,7 @@ hipError_t noalloc_scratch_for(int device, unsigned char** out) {
     if (!ptr) return hipErrorInvalidSymbol;
     g_scratch_ptr[device] = ptr;
   }
-  *out = g_scratch_ptr[device];
+  *out = g_scratch_ptr[device] + (size_t)(g_scene_ordinal[device]++ % RT_NOALLOC_PARTITIONS) * RT_NOALLOC_MAX_LAUNCHES * NOALLOC_SLOT_BYTES;
   return hipSuccess;
 }
 }  // namespace
@@ -629,8 +634,17 @@ struct rt_scene {
   WfCounters* wf_ctr = nullptr;   // device
   unsigned int* wf_host = nullptr;  // pinned: the `retired` count as last read
   uint32_t wf_trace_blocks = 0;
-  DeviceStats* dstats = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // Counter blocks (DeviceStats: work counters + the persistent kernels' unit counter) of the render calls: a ring of
+  // RING_CHUNKS chunks of RING_CHUNK_SLOTS 256-byte slots.  Every call takes the next chunk for itself, so that calls
+  // enqueued on different streams (or from different threads) on ONE scene do not share counters; a chunk is reused
+  // after RING_CHUNKS further calls, by which time a caller must have let the earlier call finish.
+  static constexpr uint32_t RING_CHUNKS = 16, RING_CHUNK_SLOTS = 16;
+  unsigned char* dstats = nullptr;
+  std::atomic<uint32_t> ring_next{0};
+  unsigned char* next_chunk() {
+    return dstats + (size_t)(ring_next.fetch_add(1, std::memory_order_relaxed) % RING_CHUNKS) * RING_CHUNK_SLOTS * NOALLOC_SLOT_BYTES;
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;  // timing events of the entries that must not allocate (and the wavefront form)
   ~rt_scene() {
     if (dstats) (void)hipFree(dstats);
     if (wf_mem) (void)hipFree(wf_mem);
@@ -876,7 +890,7 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
   s->safe_t_hi = facts.t_hi;
   if ((e = build_side<float>(*d, complexes, linear, facts, s->f32)) != hipSuccess ||
       (e = build_side<double>(*d, complexes, linear, facts, s->f64)) != hipSuccess ||
-      (e = hipMalloc((void**)&s->dstats, sizeof(DeviceStats))) != hipSuccess ||
+      (e = hipMalloc((void**)&s->dstats, (size_t)rt_scene::RING_CHUNKS * rt_scene::RING_CHUNK_SLOTS * NOALLOC_SLOT_BYTES)) != hipSuccess ||
       (e = hipEventCreate(&s->ev0)) != hipSuccess || (e = hipEventCreate(&s->ev1)) != hipSuccess) {
     delete s;
     return fail(RT_ERR_HIP, "rt_scene_create: upload failed: %s", hipGetErrorString(e));
@@ -1089,6 +1103,9 @@ int check_params(const rt_params* p, const char* who) {
   if (p->width < 2 || p->height < 2)
     return fail(RT_ERR_BAD_ARG, "%s: image must be at least 2x2 (main.rs:161-163 divides by w-1, h-1)", who);
   if ((uint64_t)p->width * p->height > 0xFFFFFFFFull / 3) return fail(RT_ERR_BAD_ARG, "%s: image too large", who);
+  // the persistent kernels pack a unit's tile origin as x | y << 16
+  if (p->width > 65535u || p->height > 65535u)
+    return fail(RT_ERR_BAD_ARG, "%s: image width and height must not exceed 65535 pixels", who);
   if (p->sample_offset + p->spp > 0xFFFFFFFFull) return fail(RT_ERR_BAD_ARG, "%s: sample index exceeds 32 bits", who);
   return RT_OK;
 }
@@ -1097,6 +1114,7 @@ int check_params(const rt_params* p, const char* who) {
 // iterations to read how many pool slots have retired (the host decides when the pool has drained).
 int render_wavefront(rt_scene* s, const rt_camera* cam, const rt_params* p, float* d_accum, int accumulate, hipStream_t stream,
                      rt_stats* stats, const LaunchShape& shape) {
+  DeviceStats* const dstats = reinterpret_cast<DeviceStats*>(s->next_chunk());
   const bool want_stats = (p->flags & RT_FLAG_STATS) != 0;
   static const char* slots_env = getenv("RT_WF_SLOTS");
   const uint32_t max_slots = slots_env ? (uint32_t)std::max(256, atoi(slots_env)) : (1u << 21);
@@ -1150,7 +1168,7 @@ int render_wavefront(rt_scene* s, const rt_camera* cam, const rt_params* p, floa
   }
   const CameraView<float> cv = to_camera<float>(*cam);
   const size_t accum_bytes = (size_t)p->width * p->height * 3 * sizeof(float);
-  HIP_TRY(hipMemsetAsync(s->dstats, 0, sizeof(DeviceStats), stream));
+  HIP_TRY(hipMemsetAsync(dstats, 0, sizeof(DeviceStats), stream));
   HIP_TRY(hipMemsetAsync(s->wf_ctr, 0, sizeof(WfCounters), stream));
   if (!accumulate) HIP_TRY(hipMemsetAsync(d_accum, 0, accum_bytes, stream));
   HIP_TRY(hipEventRecord(s->ev0, stream));
@@ -1166,7 +1184,7 @@ int render_wavefront(rt_scene* s, const rt_camera* cam, const rt_params* p, floa
     for (uint32_t k = 0; k < check_every; ++k, ++iter) {
       a.in_list = a.out_list;  // (a list exists once an iteration has written it)
       a.out_list = tail ? 1u : 0u;
-      HIP_TRY(launch_wf_iteration(s->f32.view, cv, a, pool, s->wf_ctr, iter & 1u, d_accum, s->dstats, want_stats, trace_blocks,
+      HIP_TRY(launch_wf_iteration(s->f32.view, cv, a, pool, s->wf_ctr, iter & 1u, d_accum, dstats, want_stats, trace_blocks,
                                   stream));
     }
     HIP_TRY(hipMemcpyAsync(s->wf_host, &s->wf_ctr->retired, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
@@ -1178,7 +1196,7 @@ int render_wavefront(rt_scene* s, const rt_camera* cam, const rt_params* p, floa
   HIP_TRY(hipEventRecord(s->ev1, stream));
   if (stats) {
     DeviceStats hs;
-    HIP_TRY(hipMemcpyAsync(&hs, s->dstats, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&hs, dstats, sizeof(hs), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     std::memset(stats, 0, sizeof(*stats));
     stats_to_abi(hs, stats);
@@ -1191,13 +1209,15 @@ int render_wavefront(rt_scene* s, const rt_camera* cam, const rt_params* p, floa
 }
 
 // Enqueue the launches of one render call on `stream`; accum is device memory.
-// blocks / n_blocks: the DeviceStats scratch.  n_blocks == 1 (the scene's own block, allocated by rt_scene_create):
-// every launch uses it, its unit counter is re-zeroed between launches.  n_blocks > 1 (rt_render_device_noalloc: the
-// file-scope scratch, 256-byte slots): launch i uses slot i, all slots are zeroed by one memset up front and the
-// counters are summed on the host.
+// Counter blocks (DeviceStats, one 256-byte slot each).  The ordinary entries take the scene's next ring chunk
+// (rt_scene::next_chunk: RING_CHUNK_SLOTS slots of this call's own); rt_render_device_noalloc passes its partition of
+// the file-scope scratch (`noalloc`, n_slots = RT_NOALLOC_MAX_LAUNCHES) and is refused if it needs more launches than
+// that.  Launch i uses slot i % n_slots; all slots are zeroed by one kernel up front, a slot that is used again has its
+// unit counter re-zeroed first (launches of one call are ordered on the stream), and the work counters — which simply
+// keep adding up in a reused slot — are summed over the slots on the host.
 template <typename R>
 int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d_accum, int accumulate,
-                     hipStream_t stream, rt_stats* stats, unsigned char* blocks = nullptr, uint32_t n_blocks = 1) {
+                     hipStream_t stream, rt_stats* stats, unsigned char* noalloc = nullptr, uint32_t n_slots = 0) {
   if (!s || !p || !d_accum) return fail(RT_ERR_BAD_ARG, "rt_render: null argument");
   if (int rc = check_camera(cam)) return rc;
   if (int rc = check_params(p, "rt_render")) return rc;
@@ -1206,14 +1226,11 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
   // samples one by one (measured on Cornell 1024^2 x 4096 spp: 64 per launch 40.3, 256: 43.1, 4096: 45.2 Grays/s).
   const uint32_t per_launch = p->spp_per_launch ? p->spp_per_launch : 4096u;
   const uint32_t n_launches = (p->spp + per_launch - 1) / per_launch;
-  const bool slots = blocks != nullptr;
-  if (slots && n_launches > n_blocks)
+  if (noalloc && n_launches > n_slots)
     return fail(RT_ERR_BAD_ARG,
                 "rt_render_device_noalloc: %u spp at %u per launch is %u launches, the static scratch holds %u: raise "
                 "spp_per_launch or split the call",
-                p->spp, per_launch, n_launches, n_blocks);
-  if (!slots) blocks = reinterpret_cast<unsigned char*>(s->dstats);
-  auto block = [&](uint32_t i) { return reinterpret_cast<DeviceStats*>(blocks + (slots ? (size_t)i * NOALLOC_SLOT_BYTES : 0)); };
+                p->spp, per_launch, n_launches, n_slots);
   HIP_TRY(hipSetDevice(s->device));
   const bool want_stats = (p->flags & RT_FLAG_STATS) != 0;
   if constexpr (sizeof(R) == 4) {
@@ -1221,18 +1238,46 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
     // the entry that must not allocate
     static const bool wavefront_env = getenv("RT_WAVEFRONT") != nullptr;
     const bool wavefront = wavefront_env || (p->flags & RT_FLAG_WAVEFRONT) != 0;
-    if (wavefront && !slots && p->spp > 0 && !(p->flags & RT_FLAG_FORCE_BVH)) {
+    if (wavefront && !noalloc && p->spp > 0 && !(p->flags & RT_FLAG_FORCE_BVH)) {
       const LaunchShape sh0 = make_shape(s, p->width, p->height, p->spp, true, cam, p->max_depth);
-      if (sh0.trav == 2) return render_wavefront(s, cam, p, (float*)d_accum, accumulate, stream, stats, sh0);
+      // (its job cursors are 32-bit, one per 1/64 of the jobs: a shard hands out about n_tiles x spp of them — beyond
+      // that the call stays on the megakernel)
+      const uint64_t shard_jobs = (uint64_t)((p->width + 7) / 8) * ((p->height + 7) / 8) * p->spp;
+      if (sh0.trav == 2 && shard_jobs < 0xFFF00000ull)
+        return render_wavefront(s, cam, p, (float*)d_accum, accumulate, stream, stats, sh0);
     }
   }
+  unsigned char* const blocks = noalloc ? noalloc : s->next_chunk();
+  if (!noalloc) n_slots = rt_scene::RING_CHUNK_SLOTS;
+  const uint32_t used = std::max(1u, std::min(n_launches, n_slots));
+  auto block = [&](uint32_t i) { return reinterpret_cast<DeviceStats*>(blocks + (size_t)(i % used) * NOALLOC_SLOT_BYTES); };
   CameraView<R> cv = to_camera<R>(*cam);
   const SceneView<R>& sv = Side<R>::get(s).view;
   static_assert(sizeof(DeviceStats) % 4 == 0 && NOALLOC_SLOT_BYTES % 4 == 0, "cleared in dwords");
-  HIP_TRY(launch_zero(blocks, slots ? std::max<size_t>(n_launches, 1) * NOALLOC_SLOT_BYTES : sizeof(DeviceStats), stream));
-  // (the two timing events only when somebody will read them: without stats the call is memsets and launches,
-  // nothing else — what a caller that captures it into a HIP graph wants to see on its stream)
-  if (stats) HIP_TRY(hipEventRecord(s->ev0, stream));
+  HIP_TRY(launch_zero(blocks, (size_t)used * NOALLOC_SLOT_BYTES, stream));
+  // Timing events only when somebody will read them: without stats the call is kernels only — what a caller that
+  // captures it into a HIP graph wants to see on its stream.  The ordinary entries create this call's own pair (two
+  // calls on one scene may be timed at once); the entry that must not allocate uses the scene's.
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  struct EventPair {
+    hipEvent_t *a, *b;
+    bool owned;
+    ~EventPair() {
+      if (owned && *a) (void)hipEventDestroy(*a);
+      if (owned && *b) (void)hipEventDestroy(*b);
+    }
+  } pair{&ev0, &ev1, false};
+  if (stats) {
+    if (noalloc) {
+      ev0 = s->ev0;
+      ev1 = s->ev1;
+    } else {
+      pair.owned = true;
+      HIP_TRY(hipEventCreate(&ev0));
+      HIP_TRY(hipEventCreate(&ev1));
+    }
+    HIP_TRY(hipEventRecord(ev0, stream));
+  }
   uint32_t done = 0, launches = 0;
   bool first = true;
   const size_t accum_bytes = (size_t)p->width * p->height * 3 * sizeof(R);
@@ -1242,7 +1287,7 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
     LaunchShape sh = make_shape(s, p->width, p->height, n, !(p->flags & RT_FLAG_FORCE_BVH), cam, p->max_depth, sizeof(R) == 8);
     int acc = (accumulate || !first) ? 1 : 0;
     if ((sh.splits > 1 || sh.unit_samples > 0) && !acc) HIP_TRY(launch_zero(d_accum, accum_bytes, stream));
-    if (sh.unit_samples > 0 && !slots && !first) HIP_TRY(launch_zero(&s->dstats->unit_counter, sizeof(unsigned int), stream));
+    if (sh.unit_samples > 0 && launches >= used) HIP_TRY(launch_zero(&block(launches)->unit_counter, sizeof(unsigned int), stream));
     HIP_TRY(Side<R>::render(sv, cv, p->width, p->height, (uint32_t)(p->sample_offset + done), n, p->max_depth, p->seed,
                             acc, want_stats, d_accum, block(launches), sh, stream));
     done += n;
@@ -1250,23 +1295,19 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
     ++launches;
   }
   if (stats) {
-    HIP_TRY(hipEventRecord(s->ev1, stream));
+    HIP_TRY(hipEventRecord(ev1, stream));
     DeviceStats hs;
     std::memset(&hs, 0, sizeof(hs));
-    if (!slots) {
-      HIP_TRY(hipMemcpyAsync(&hs, s->dstats, sizeof(hs), hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-    } else {
-      static_assert(NOALLOC_SLOT_BYTES * RT_NOALLOC_MAX_LAUNCHES <= 64 * 1024, "the slot image is read back through the stack");
-      alignas(16) unsigned char image[NOALLOC_SLOT_BYTES * RT_NOALLOC_MAX_LAUNCHES];
-      if (launches) HIP_TRY(hipMemcpyAsync(image, blocks, (size_t)launches * NOALLOC_SLOT_BYTES, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-      for (uint32_t i = 0; i < launches; ++i) {
-        DeviceStats one;
-        std::memcpy(&one, image + (size_t)i * NOALLOC_SLOT_BYTES, sizeof(one));
-        for (int k = 0; k < 17; ++k) hs.v[k] += one.v[k];
-        for (int k = 0; k < 8; ++k) hs.stamp[k] += one.stamp[k];
-      }
+    static_assert(NOALLOC_SLOT_BYTES * RT_NOALLOC_MAX_LAUNCHES <= 64 * 1024, "the slot image is read back through the stack");
+    alignas(16) unsigned char image[NOALLOC_SLOT_BYTES * RT_NOALLOC_MAX_LAUNCHES];
+    static_assert(rt_scene::RING_CHUNK_SLOTS <= RT_NOALLOC_MAX_LAUNCHES, "a ring chunk fits the read-back image");
+    HIP_TRY(hipMemcpyAsync(image, blocks, (size_t)used * NOALLOC_SLOT_BYTES, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (uint32_t i = 0; i < used; ++i) {
+      DeviceStats one;
+      std::memcpy(&one, image + (size_t)i * NOALLOC_SLOT_BYTES, sizeof(one));
+      for (int k = 0; k < 17; ++k) hs.v[k] += one.v[k];
+      for (int k = 0; k < 8; ++k) hs.stamp[k] += one.stamp[k];
     }
     std::memset(stats, 0, sizeof(*stats));
     stats_to_abi(hs, stats);
@@ -1276,7 +1317,7 @@ int render_on_device(rt_scene* s, const rt_camera* cam, const rt_params* p, R* d
       fprintf(stderr, "\n");
     }
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
     stats->kernel_ms = ms;
     stats->launches = launches;
   }

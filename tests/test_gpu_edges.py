@@ -34,6 +34,15 @@ def test_sample_ranges_compose(name, sid, asp, kw):
     tol = dict(rtol=1e-12, atol=1e-12) if kw.get("f64") else dict(rtol=2e-5, atol=1e-5)
     np.testing.assert_allclose(a + b, whole, **tol)
     np.testing.assert_allclose(c, whole, **tol)
+    # more launches than a call has counter slots (16): a slot is used again, its unit counter re-zeroed in between,
+    # and the work counters keep adding up
+    d, sd = ds.render(w, h, 16, 8, seed=4, sample_offset=100, spp_per_launch=1 if not kw.get("f64") else 1, stats=True, **kw)
+    assert sd["launches"] == 16 + 0 and sd["rays"] == sw["rays"]
+    e, se = ds.render(w, h, 40, 8, seed=4, sample_offset=100, spp_per_launch=2, stats=True, **kw)
+    f, sf = ds.render(w, h, 40, 8, seed=4, sample_offset=100, stats=True, **kw)
+    assert se["launches"] == 20 and se["rays"] == sf["rays"] and se["closest_hits"] == sf["closest_hits"]
+    np.testing.assert_allclose(d, whole, **tol)
+    np.testing.assert_allclose(e, f, **(dict(rtol=1e-12, atol=1e-12) if kw.get("f64") else dict(rtol=5e-5, atol=2e-5)))
 
 
 @pytest.mark.parametrize("name,sid,asp,kw", FAMILIES)
@@ -109,6 +118,15 @@ def test_arguments_are_validated_not_trusted():
         ds.render(8, 8, 16, 1, sample_offset=0xFFFFFFF8)
     tiny, st = ds.render(2, 2, 3, 4, stats=True)  # the smallest legal image
     assert tiny.shape == (2, 2, 3) and st["rays"] >= 12
+    # a tile origin is packed as x | y << 16 by the persistent kernels: wider or taller than 65535 is refused, not
+    # rendered into the wrong pixels; 65535 itself renders (every kernel family packs origins the same way)
+    for fam in ({}, {"f64": True}):
+        with pytest.raises(RuntimeError, match="65535"):
+            ds.render(65537, 2, 1, 2, **fam)
+        with pytest.raises(RuntimeError, match="65535"):
+            ds.render(2, 65536, 1, 2, **fam)
+    wide, sw = ds.render(65535, 2, 1, 2, stats=True)
+    assert sw["rays"] >= 2 * 65535 and np.isfinite(wide).all() and wide[:, -8:].sum() >= 0
 
 
 def test_non_sphere_light_follows_hittable_rs_498_513():
@@ -478,3 +496,37 @@ def test_two_scenes_on_two_streams_overlap_without_interference():
         a.render_device(both.data_ptr(), w, ha, 128, 50, seed=7, want_stats=False)
         torch.cuda.synchronize()
         np.testing.assert_allclose(out_a.cpu().numpy(), both.cpu().numpy(), rtol=3e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("sid,asp,kw", [(6, 1.0, {}), (0, 16 / 9, {}), (6, 1.0, {"f64": True})])
+def test_one_scene_on_two_streams_overlaps_without_interference(sid, asp, kw):
+    """include/rt.h "STREAMS AND THREADS": every render call takes a counter block of its own (the persistent kernels'
+    unit counter lives there), so two calls on ONE rt_scene enqueued on two streams without a host wait in between —
+    they overlap on the GPU — each render every unit exactly once: both images equal the scene's lone render of the
+    same samples (persistent leaf-list kernel, units kernel, f64 kernel)."""
+    import torch
+    import raytracer_amd as R
+    ds = R.DeviceScene(R.HostScene(sid, asp), 0)
+    w = 192
+    h = R.image_height(w, asp)
+    dt = torch.float64 if kw else torch.float32
+    spp = 96 if not kw else 32
+    refs = []
+    for off in (0, 1000):
+        r = torch.zeros((h, w, 3), dtype=dt, device="cuda:0")
+        ds.render_device(r.data_ptr(), w, h, spp, 50, seed=9, sample_offset=off, want_stats=False, **kw)
+        torch.cuda.synchronize()
+        refs.append(r.cpu().numpy())
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    o1 = torch.zeros((h, w, 3), dtype=dt, device="cuda:0")
+    o2 = torch.zeros_like(o1)
+    for _ in range(3):
+        o1.fill_(-5.0)
+        o2.fill_(-5.0)
+        torch.cuda.synchronize()
+        ds.render_device(o1.data_ptr(), w, h, spp, 50, seed=9, sample_offset=0, want_stats=False, stream=s1.cuda_stream, **kw)
+        ds.render_device(o2.data_ptr(), w, h, spp, 50, seed=9, sample_offset=1000, want_stats=False, stream=s2.cuda_stream, **kw)
+        torch.cuda.synchronize()
+        tol = dict(rtol=1e-11, atol=1e-11) if kw else dict(rtol=3e-5, atol=1e-4)
+        np.testing.assert_allclose(o1.cpu().numpy(), refs[0], **tol)
+        np.testing.assert_allclose(o2.cpu().numpy(), refs[1], **tol)

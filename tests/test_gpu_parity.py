@@ -126,9 +126,13 @@ def _chunk_means(render_chunk, spp, chunks, clip):
     return ms.mean(axis=0), ms.std(axis=0, ddof=1) / np.sqrt(chunks)
 
 
-@pytest.mark.parametrize("name", ["random_scene", "simple_light", "cornell_box", "earth", "small_scene", "final_scene",
-                                  "bvh_stress", "perlin_spheres", "cornell_box_area", "area_light_plate", "area_light_list"])
-def test_render_f32_within_monte_carlo_noise(name, earthmap):
+@pytest.mark.parametrize("name,wavefront", [(n, False) for n in (
+    "random_scene", "simple_light", "cornell_box", "earth", "small_scene", "final_scene", "bvh_stress", "perlin_spheres",
+    "cornell_box_area", "area_light_plate", "area_light_list")] + [
+    # the wavefront-queue form (RT_FLAG_WAVEFRONT) against the ORACLE (main.rs:65-105), not only against
+    # its sibling kernel (tests/test_gpu_wavefront.py)
+    ("random_scene", True), ("final_scene", True), ("bvh_stress", True)])
+def test_render_f32_within_monte_carlo_noise(name, wavefront, earthmap):
     """f32 production kernel vs oracle, different seeds, matched spp (main.rs:160-167's estimator): the
     difference of two independent estimates must look like noise of the MEASURED per-pixel variance —
     per pixel channel, z = |gpu - oracle| / sqrt(se_gpu^2 + se_oracle^2) with the standard errors taken from
@@ -140,7 +144,15 @@ def test_render_f32_within_monte_carlo_noise(name, earthmap):
     # final_scene / bvh_stress: the reference's estimator has fireflies of 1e20 and more (fog gains energy per
     # scatter; glass next to the sky): compare chunk means clipped to the displayable range
     clip = 4.0 if name in ("final_scene", "bvh_stress") else 0.0
-    g, sg = _chunk_means(lambda off, n: ds.render(W, h, n, depth, seed=21, sample_offset=off)[0], spp, chunks, clip)
+    launches = []
+
+    def gpu_chunk(off, n):
+        img, st = ds.render(W, h, n, depth, seed=21, sample_offset=off, wavefront=wavefront, stats=wavefront)
+        launches.append(st["launches"])
+        return img
+    g, sg = _chunk_means(gpu_chunk, spp, chunks, clip)
+    if wavefront:
+        assert min(launches) >= 3, "RT_FLAG_WAVEFRONT did not take the wavefront form (1 + 2 launches per bounce)"
     o, so = _chunk_means(lambda off, n: os_.render(W, h, n, depth, seed=22, sample_offset=off)[0], spp, chunks, clip)
     sig = np.sqrt(sg * sg + so * so)
     # pixels without real spread in either estimate (background, saturated emitters: every sample the same number

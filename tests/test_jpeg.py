@@ -77,6 +77,46 @@ def test_refuses_what_it_cannot_decode(tmp_path):
         R.texture_from_file(str(tmp_path / "missing.jpg"))
 
 
+def test_hostile_files_are_refused_or_decoded_never_trusted(tmp_path):
+    """Truncated and corrupt variants of the reference's asset: every one is either refused with an RtError or decoded
+    to an image of the right shape — never a crash, an over-read or an overflow (the advisor's cases: an SOS of length 2
+    at the end of the file, a second SOF, 16-bit quantisation tables, a corrupt DC run)."""
+    data = bytes(open(JPG, "rb").read())
+    sof, sos, dqt = data.find(b"\xff\xc0"), data.find(b"\xff\xda"), data.find(b"\xff\xdb")
+    assert 0 < dqt < sof < sos
+    sof_len = (data[sof + 2] << 8) | data[sof + 3]
+    frame = data[sof:sof + 2 + sof_len]
+    cases = {
+        "sos_len2_at_eof.jpg": data[:sos] + b"\xff\xda\x00\x02",            # s[0] would be read past the end
+        "sos_len2.jpg": data[:sos] + b"\xff\xda\x00\x02" + data[sos + 4:],
+        "two_sof.jpg": data[:sos] + frame + data[sos:],                       # hmax_/vmax_ of the first frame must not leak
+        "dqt16.jpg": data[:dqt + 4] + bytes([data[dqt + 4] | 0x10]) + data[dqt + 5:],  # Pq = 1 in a baseline file
+        "cut_in_header.jpg": data[:sof + 6],
+        "cut_after_sos_marker.jpg": data[:sos + 2],
+        "cut_in_sos.jpg": data[:sos + 5],
+    }
+    rng = np.random.default_rng(7)
+    for k in range(12):  # random bytes splashed over the entropy-coded data: corrupt DC runs, bad categories, runs past a block
+        blob = bytearray(data)
+        at = rng.integers(sos + 20, len(data) - 64)
+        blob[at:at + 48] = bytes(int(x) for x in rng.integers(0, 255, 48) if True)
+        cases[f"splash{k}.jpg"] = bytes(blob)
+    refused = 0
+    for name, blob in cases.items():
+        path = str(tmp_path / name)
+        open(path, "wb").write(blob)
+        try:
+            img = R.texture_from_file(path)
+        except R._ffi.RtError:
+            refused += 1
+            continue
+        assert img.shape == (512, 1024, 3) and img.dtype == np.uint8, name
+    assert refused >= 6  # the seven structural cases but possibly one; the splashes may decode (to garbage)
+    for name in ("sos_len2_at_eof.jpg", "sos_len2.jpg", "two_sof.jpg", "dqt16.jpg"):
+        with pytest.raises(R._ffi.RtError):
+            R.texture_from_file(str(tmp_path / name))
+
+
 def test_the_same_entry_reads_a_ppm(tmp_path):
     path = str(tmp_path / "e.ppm")
     R.write_earthmap_ppm(path)
