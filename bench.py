@@ -507,6 +507,27 @@ def main():
     return 0
 
 
+def native_oracle():
+    """the timed CPU baseline is built -O3 -march=native ON THE BOX THAT TIMES IT (the shipped
+    liboracle_nocount.so is built in another container, without -march=native).  Same sources, same flags otherwise
+    (contraction off); written to the temporary directory, never into the repository.  Returns (library, build note);
+    falls back to the shipped library when no compiler is at hand."""
+    import shutil
+    import tempfile
+    cxx = shutil.which(os.environ.get("CXX", "g++"))
+    src = os.path.join(ROOT, "oracle", "oracle_capi.cpp")
+    if cxx and os.path.exists(src):
+        out = os.path.join(tempfile.gettempdir(), f"liboracle_nocount_native_{os.getuid()}.so")
+        cmd = [cxx, "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-DORC_NO_COUNT", "-shared",
+               "-o", out, src]
+        try:
+            subprocess.run(cmd, check=True, timeout=300, capture_output=True, cwd=os.path.join(ROOT, "oracle"))
+            return out, "g++ -O3 -march=native -ffp-contract=off, built on this box"
+        except (subprocess.SubprocessError, OSError):
+            pass
+    return "liboracle_nocount.so", "g++ -O3 -ffp-contract=off (shipped build, no -march=native: no compiler on this box)"
+
+
 def cpu_baseline(args, width, height):
     """The CPU oracle (oracle/, a line-faithful f64 restatement of the reference: the Rust binary cannot
     be built here) timed on this box's host cores on a bounded sample of the same workload."""
@@ -516,7 +537,7 @@ def cpu_baseline(args, width, height):
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
     threads = max(1, min(threads, os.cpu_count() or 1))
     sid = R.SCENE_IDS[args.scene]
-    tex = R.load_earthmap() if sid in (2, 4, 8) else None
+    tex = R.load_earthmap() if sid in (2, 4, 8, 11, 16) else None
     sc = O.OracleScene(sid, args.aspect, n=args.n, texels=tex)
     # calibrate on a quarter-resolution 1-spp pass, then size the sample for ~cpu_seconds
     cw, ch = max(2, width // 4), max(2, height // 4)
@@ -527,9 +548,10 @@ def cpu_baseline(args, width, height):
     # rays of the sample: counted by the checker build (liboracle.so); time: the same sources built without the
     # work counters (liboracle_nocount.so, ~1.3x faster), same seed, so the same paths
     _, cnt, secs_counted = sc.render(width, height, spp, args.max_depth, seed=1, threads=threads)
-    fast = O.OracleScene(sid, args.aspect, n=args.n, texels=tex, library="liboracle_nocount.so")
+    library, build_note = native_oracle()
+    fast = O.OracleScene(sid, args.aspect, n=args.n, texels=tex, library=library)
     _, _, secs = fast.render(width, height, spp, args.max_depth, seed=1, threads=threads)
-    return {"value": cnt["rays"] / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    return {"value": cnt["rays"] / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "build": build_note,
             "sample": f"{args.scene} {width}x{height} at {spp} spp, depth {args.max_depth} ({secs:.1f} s, "
                       f"{cnt['rays']} rays; {secs_counted:.1f} s with the checker's work counters on); "
                       "rates are spp-independent",

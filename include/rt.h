@@ -25,8 +25,10 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2u  /* 2: rt_scene_desc.light_box, RT_LIGHT_CUBE, RT_MAT_AREA_LIGHT */
-#define RT_MAX_BVH_HEIGHT 63u       /* nodes on a root-to-leaf path: 4 B per level and lane of LDS, 64 KiB per workgroup */
+#define RT_ABI_VERSION 3u  /* 2: rt_scene_desc.light_box, RT_LIGHT_CUBE, RT_MAT_AREA_LIGHT; 3: complex_body may be a node
+                              (an instance: wrappers over a sub-tree) */
+#define RT_MAX_BVH_HEIGHT 63u       /* nodes on a root-to-leaf path (through an instance: + 1 + its sub-tree's): 4 B per level
+                                       and lane of LDS, 64 KiB per workgroup */
 #define RT_NOALLOC_MAX_LAUNCHES 63u /* rt_render_device_noalloc: kernel launches per call (256 B of static scratch each) */
 #define RT_NOALLOC_PARTITIONS 4u    /* ... and how many scenes of one GPU have a partition of that scratch to themselves */
 
@@ -36,7 +38,8 @@ typedef enum rt_status {
   RT_OK = 0,
   RT_ERR_BAD_ARG = 1,      /* null pointer, size mismatch, out-of-range index, empty shutter */
   RT_ERR_HIP = 2,          /* a hip* call failed (no device, OOM, launch failure) */
-  RT_ERR_UNSUPPORTED = 3,  /* scene uses nesting the flat format cannot express */
+  RT_ERR_UNSUPPORTED = 3,  /* scene uses nesting the flat format cannot express (a medium in a medium, an instance in
+                              an instance, a medium whose boundary is a sub-tree) */
   RT_ERR_STACK_DEPTH = 4   /* BVH height exceeds the LDS traversal stack (RT_MAX_BVH_HEIGHT) */
 } rt_status;
 
@@ -55,7 +58,8 @@ enum rt_leaf_kind {
   RT_LEAF_MSPHERE = 1,  /* Hittable::MovingSphere  hittable.rs:56-72, 288-318 */
   RT_LEAF_CUBE = 2,     /* Hittable::Cube          hittable.rs:42-47, 210-256 */
   RT_LEAF_COMPLEX = 3   /* a chain of Translate / Rotate / ConstantMedium wrappers
-                           (hittable.rs:74-91, 319-386) around one of the above */
+                           (hittable.rs:74-91, 319-386) around one of the above — or, Translate /
+                           Rotate only, around a whole sub-tree (an INSTANCE: complex_body below) */
 };
 
 enum rt_op_tag {        /* one wrapper of a complex object's chain, outermost first */
@@ -135,7 +139,13 @@ typedef struct rt_scene_desc {
   const uint32_t* cube_object;
 
   uint32_t n_complex;
-  const uint32_t* complex_body;       /* leaf ref of kind SPHERE / MSPHERE / CUBE */
+  const uint32_t* complex_body;       /* leaf ref of kind SPHERE / MSPHERE / CUBE; or (no RT_REF_LEAF) the index of a
+                                         NODE: the root of a sub-tree of its own that the wrappers hold, as
+                                         hittable.rs:81-91 hold a Box<Hittable> that is a Bvh (an instance).  Its nodes
+                                         live in the node arrays behind the node that references the complex, its
+                                         boxes are in the wrappers' inner frame, its leaves are bare primitives; no
+                                         RT_OP_MEDIUM in such a chain, no instance inside an instance
+                                         (RT_ERR_UNSUPPORTED) */
   const uint32_t* complex_op_first;   /* first wrapper in ops[] */
   const uint32_t* complex_op_count;   /* number of wrappers, outermost first */
   const uint32_t* complex_material;   /* Isotropic material of the medium op, else RT_REF_NONE */

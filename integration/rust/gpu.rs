@@ -8,7 +8,7 @@ use image::RgbImage;
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RT_ABI_VERSION: u32 = 2;
+pub const RT_ABI_VERSION: u32 = 3;
 pub const RT_REF_LEAF: u32 = 0x8000_0000;
 pub const RT_REF_NONE: u32 = 0xFFFF_FFFF;
 pub const fn make_leaf(kind: u32, index: u32) -> u32 { RT_REF_LEAF | (kind << 28) | index }

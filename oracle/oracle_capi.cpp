@@ -2,6 +2,7 @@
 //
 // C entry points over the CPU restatement, for ctypes (tests/, __graft_entry__.smoke(),
 // bench.py's cpu_baseline leg). Nothing under raytracer_amd/ may load this library.
+#include <algorithm>
 #include <cstring>
 #include <string>
 
@@ -62,8 +63,17 @@ orc_scene* orc_scene_create(int scene_id, double aspect_ratio, uint64_t scene_se
 
 void orc_scene_destroy(orc_scene* s) { delete s; }
 
+// the Bvh behind a world-level object's Translate / Rotate wrappers (an instance), or null
+static const Hittable* instance_tree(const Hittable& h) {
+  const Hittable* c = &h;
+  while ((c->kind == Hittable::Translate || c->kind == Hittable::Rotate) && c->child) c = c->child.get();
+  return (c != &h && c->kind == Hittable::Bvh) ? c : nullptr;
+}
 static uint32_t count_nodes(const Hittable& h) {
-  if (h.kind != Hittable::Bvh) return 0;
+  if (h.kind != Hittable::Bvh) {
+    const Hittable* t = instance_tree(h);
+    return t ? count_nodes(*t) : 0;
+  }
   return 1 + count_nodes(*h.left) + count_nodes(*h.right);
 }
 
@@ -96,21 +106,44 @@ void orc_scene_info(const orc_scene* s, orc_info* out) {
 // Pre-order dump of the pointer tree: node k = (box, left ref, right ref); a ref is either a
 // node's pre-order index or 0x80000000 | object_id for a leaf.  Returns the root ref
 // (0x80000000|id for a bare 1-object world, 0xFFFFFFFF for an Empty world).
-static uint32_t dump(const Hittable& h, uint32_t& next, double* boxes, uint32_t* left, uint32_t* right) {
+// An INSTANCE (a world-level Translate / Rotate chain over a Bvh, scene 16) is a leaf of the world's tree; its own tree
+// is dumped behind the world's nodes, in the order the world's nodes reference the instances (node index order, a
+// node's left child before its right); the leaves of an instance's tree carry the instance's object id (the owner).
+struct DumpCtx {
+  uint32_t next = 0;
+  double* boxes;
+  uint32_t *left, *right;
+  std::vector<std::pair<uint32_t, const Hittable*>> node_leaves;  // (node, world-level leaf) in node order, left first
+};
+static uint32_t dump(const Hittable& h, DumpCtx& c, bool world_level) {
   if (h.kind == Hittable::Empty) return 0xFFFFFFFFu;
-  if (h.kind != Hittable::Bvh) return 0x80000000u | h.object_id;
-  uint32_t me = next++;
-  fill3(boxes + 6 * (size_t)me, h.box.minimum);
-  fill3(boxes + 6 * (size_t)me + 3, h.box.maximum);
-  uint32_t l = dump(*h.left, next, boxes, left, right);
-  uint32_t r = dump(*h.right, next, boxes, left, right);
-  left[me] = l;
-  right[me] = r;
+  if (h.kind != Hittable::Bvh) return 0x80000000u | (h.object_id != NO_OBJECT ? h.object_id : h.owner_id);
+  uint32_t me = c.next++;
+  fill3(c.boxes + 6 * (size_t)me, h.box.minimum);
+  fill3(c.boxes + 6 * (size_t)me + 3, h.box.maximum);
+  if (world_level) {
+    if (h.left->kind != Hittable::Bvh) c.node_leaves.emplace_back(me, h.left.get());
+    if (h.right->kind != Hittable::Bvh) c.node_leaves.emplace_back(me, h.right.get());
+  }
+  uint32_t l = dump(*h.left, c, world_level);
+  uint32_t r = dump(*h.right, c, world_level);
+  c.left[me] = l;
+  c.right[me] = r;
   return me;
 }
 uint32_t orc_bvh_preorder(const orc_scene* s, double* boxes, uint32_t* left, uint32_t* right) {
-  uint32_t next = 0;
-  return dump(s->scene.world, next, boxes, left, right);
+  DumpCtx c;
+  c.boxes = boxes;
+  c.left = left;
+  c.right = right;
+  const Hittable& world = s->scene.world;
+  const uint32_t root = dump(world, c, true);
+  if (world.kind != Hittable::Bvh && world.kind != Hittable::Empty) c.node_leaves.emplace_back(0u, &world);
+  std::stable_sort(c.node_leaves.begin(), c.node_leaves.end(),
+                   [](const auto& a, const auto& b) { return a.first < b.first; });
+  for (const auto& nl : c.node_leaves)
+    if (const Hittable* t = instance_tree(*nl.second)) dump(*t, c, false);
+  return root;
 }
 
 void orc_primary_hits(const orc_scene* s, uint32_t w, uint32_t h, uint64_t seed, double time,

@@ -24,16 +24,14 @@ struct Scene {
   uint32_t bvh_calls = 0;
 };
 
-// BVH split-axis stream: axis of the k-th new_bvh call with >= 2 elements.
-constexpr uint32_t BVH_KEY_HI = 0xB5A10000u;
-inline int bvh_axis(uint64_t bvh_seed, uint32_t call) {
-  Philox4 r = philox4x32_10(call, 0, 0, 0, (uint32_t)bvh_seed, (uint32_t)(bvh_seed >> 32) ^ BVH_KEY_HI);
-  return (int)(((uint64_t)r.v[0] * 3u) >> 32);
-}
+// (bvh_axis, the BVH split-axis stream, lives in scenes.h: scene 16 builds a BVH inside its scene function)
 
 inline Scene build_scene(const SceneSpec& spec, double aspect_ratio, uint64_t bvh_seed,
                          int rotate_bbox_override /* -1 scene default, 0 reference, 1 correct */) {
-  SceneDef def = build_scene_def(spec);
+  SceneSpec spec_with_build = spec;  // what a scene function that calls new_bvh itself needs (scene 16)
+  spec_with_build.bvh_seed = bvh_seed;
+  spec_with_build.rotate_bbox_override = rotate_bbox_override;
+  SceneDef def = build_scene_def(spec_with_build);
   Scene sc;
   sc.background = def.background;
   sc.rotate_bbox = def.rotate_bbox;

@@ -66,7 +66,25 @@ struct SceneSpec {
   uint32_t n = 0;           // scene 7: number of random spheres
   std::shared_ptr<const std::vector<uint8_t>> texels;  // earthmap RGB8 for scenes 2, 4, 8
   uint32_t tex_w = 0, tex_h = 0;
+  // scenes that build a BVH of their own inside the scene function (an instance: scene 16) need what main.rs passes
+  // to the world's new_bvh (main.rs:125): the axis stream's seed and the Rotate-bbox policy
+  uint64_t bvh_seed = 7;
+  int rotate_bbox_override = -1;
 };
+
+// BVH split-axis stream: axis of the k-th new_bvh call with >= 2 elements (stands in for gen_range(0..3), hittable.rs:161).
+constexpr uint32_t BVH_KEY_HI = 0xB5A10000u;
+inline int bvh_axis(uint64_t bvh_seed, uint32_t call) {
+  Philox4 r = philox4x32_10(call, 0, 0, 0, (uint32_t)bvh_seed, (uint32_t)(bvh_seed >> 32) ^ BVH_KEY_HI);
+  return (int)(((uint64_t)r.v[0] * 3u) >> 32);
+}
+
+// The axis stream of a BVH built INSIDE a scene function (hittable.rs:159-206 called from scenes.rs-style code) for the
+// world-level object with index `world_index`: its own keyed stream, so that the world's stream (main.rs:125) is the
+// same with or without instances.  The host layer (rth_scene.cpp: instance_bvh_seed) uses the same rule.
+inline uint64_t instance_bvh_seed(uint64_t bvh_seed, uint32_t world_index) {
+  return bvh_seed + 0x9E3779B97F4A7C15ull * (uint64_t)(world_index + 1u);
+}
 
 struct SceneDef {
   std::vector<Hittable> world, lights;
@@ -312,7 +330,12 @@ inline void bvh_stress(SceneDef& s, uint64_t seed, uint32_t n) {
 // a 20×20 floor of Cubes, a Sphere light, a MovingSphere, glass, metal, two
 // ConstantMedium(Sphere) volumes, an earthmap sphere, a checker sphere in place of Perlin
 // noise, and 1000 small white spheres each wrapped Translate(Rotate(Sphere)).
-inline void final_scene(SceneDef& s, const SceneSpec& spec, bool perlin = false) {
+inline void final_scene(SceneDef& s, const SceneSpec& spec, bool perlin = false, bool instanced = false);
+// scene 16: the same composition with the book's structure for the 1000 small spheres — ONE
+// Translate(Rotate(Bvh(spheres))) instance (hittable.rs:81-91 over hittable.rs:93-98), built by Hittable::new_bvh inside
+// the scene function as "The Next Week" does with its BvhNode
+inline void final_scene_instanced(SceneDef& s, const SceneSpec& spec) { final_scene(s, spec, false, true); }
+inline void final_scene(SceneDef& s, const SceneSpec& spec, bool perlin, bool instanced) {
   Rng rng = scene_rng(spec.scene_seed, 0);
   Material ground = Material::lambertian(V3(0.48, 0.83, 0.53));
   const int boxes_per_side = 20;
@@ -349,13 +372,29 @@ inline void final_scene(SceneDef& s, const SceneSpec& spec, bool perlin = false)
       Material::lambertian_tex(perlin ? Texture::noise(NoiseTable::make(noise_rng), 0.1)
                                       : Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9)))));
   Material white = Material::lambertian(V3(0.73, 0.73, 0.73));
+  std::vector<Hittable> cluster;
   for (int j = 0; j < 1000; ++j) {
     double px = rng.range(0.0, 165.0);
     double py = rng.range(0.0, 165.0);
     double pz = rng.range(0.0, 165.0);
+    if (instanced) {
+      cluster.push_back(Hittable::new_sphere(V3(px, py, pz), 10.0, white));
+      continue;
+    }
     s.world.push_back(Hittable::new_translate(
         Hittable::new_rotate(Hittable::new_sphere(V3(px, py, pz), 10.0, white), to_radians(-15.0),
                              V3(0.0, 1.0, 0.0)),
+        V3(-100.0, 270.0, 395.0)));
+  }
+  if (instanced) {
+    BuildCtx ctx;
+    ctx.time_start = 0.0;
+    ctx.time_end = 1.0;
+    ctx.rotate_bbox = spec.rotate_bbox_override == 0 ? RotateBBox::Reference : RotateBBox::Correct;
+    const uint64_t seed = instance_bvh_seed(spec.bvh_seed, (uint32_t)s.world.size());
+    ctx.axis_of_call = [seed](uint32_t k) { return bvh_axis(seed, k); };
+    s.world.push_back(Hittable::new_translate(
+        Hittable::new_rotate(Hittable::new_bvh(cluster, ctx), to_radians(-15.0), V3(0.0, 1.0, 0.0)),
         V3(-100.0, 270.0, 395.0)));
   }
   s.cam = {V3(478.0, 278.0, -600.0), V3(278.0, 278.0, 0.0), V3(0.0, 1.0, 0.0), 40.0, 0.0, 10.0, 0.0, 1.0};
@@ -489,6 +528,7 @@ inline SceneDef build_scene_def(const SceneSpec& spec) {
     case 13: area_light_plate(s); break;
     case 14: random_scene_stdrng(s, spec.scene_seed); break;
     case 15: area_light_list(s); break;
+    case 16: final_scene_instanced(s, spec); break;
     default: small_scene(s); break;
   }
   return s;

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 RT_REF_LEAF = 0x80000000
 RT_REF_NONE = 0xFFFFFFFF
 RT_LEAF_SPHERE, RT_LEAF_MSPHERE, RT_LEAF_CUBE, RT_LEAF_COMPLEX = 0, 1, 2, 3

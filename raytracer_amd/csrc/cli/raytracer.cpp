@@ -56,7 +56,7 @@ const char* USAGE =
     "        --scene-seed <n>      scene generator seed (scenes.rs:64 uses 5) [default: 5]\n"
     "        --bvh-seed <n>        BVH split-axis stream [default: 7]\n"
     "        --n <n>               scene 7 (bvh_stress): number of spheres\n"
-    "        --earthmap <file>     the earth texture of scenes 2, 4, 8, 11: a baseline JPEG or a binary PPM (P6)\n"
+    "        --earthmap <file>     the earth texture of scenes 2, 4, 8, 11, 16: a baseline JPEG or a binary PPM (P6)\n"
     "                              [default: assets/earthmap.jpg]\n"
     "    scenes: 0 random_scene, 1 two_spheres, 2 earth, 3 simple_light, 4 cube_scene, 6 cornell_box,\n"
     "            7 bvh_stress, 8 final_scene, 9 mixed_scene (test generator), 10 perlin_spheres and\n"
@@ -192,7 +192,7 @@ int main(int argc, char** argv) {
     uint8_t*& p;
     ~TexelGuard() { rth_texture_free(p); }
   } texel_guard{texels};
-  if (o.scene == 2 || o.scene == 4 || o.scene == 8 || o.scene == 11) {  // Texture::new_image (texture.rs:25-31, scenes.rs:126)
+  if (o.scene == 2 || o.scene == 4 || o.scene == 8 || o.scene == 11 || o.scene == 16) {  // Texture::new_image (texture.rs:25-31, scenes.rs:126)
     if (rth_texture_from_image_file(o.earthmap.c_str(), &ro.scene.tex_width, &ro.scene.tex_height, &texels) != RT_OK) {
       std::fprintf(stderr, "error: scene %u needs the earth texture (scenes.rs:126): %s\n", o.scene, rth_last_error());
       return 1;

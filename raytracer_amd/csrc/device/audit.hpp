@@ -320,6 +320,9 @@ RT_DEV uint32_t traverse_audit(const SceneView<float>& sc, const SceneView<doubl
         cur = n.left;
         continue;
       }
+    } else if (sc.has_instances && ref_kind(cur) == LEAF_COMPLEX && (sc.complexes[ref_index(cur)].flags & CXF_INSTANCE)) {
+      // an instance (a sub-tree behind a rigid map): not audited — a ray whose walk reaches one is re-decided in f64
+      unsure |= AUD_ACCURACY;
     } else {
       const Cand c = audit_leaf(sc, sc64, cur, r, r64, world, t_min, closest, e_best, rng, best_sphere);
       unsure |= c.unsure;

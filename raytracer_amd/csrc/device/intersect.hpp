@@ -373,32 +373,39 @@ RT_DEV bool leaf_t_unified(const SceneView<float>& sc, uint32_t ref, const RayT<
   return true;
 }
 
-#ifndef RT_TRAVERSE_PHASED
-#define RT_TRAVERSE_PHASED 1
-#endif
+template <typename R> RT_DEV uint32_t leaf_rank(const SceneView<R>& sc, uint32_t ref);
 // world.hit(r, t_min, +inf) — hittable.rs:400-412 as an iterative DFS.  `stack` is this
 // lane's column of the LDS stack: entry i lives at stack[i * stride].
-template <typename R, bool STATS>
-RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, uint32_t* stack,
-                     uint32_t stride, R& closest, uint32_t& best, Cnt<STATS>& cnt) {
+// Same per-lane visiting order as the recursion, run in two wave phases: every lane first descends through inner nodes
+// until it stands at a leaf (or has nothing left), then the lanes at a leaf run their leaf tests TOGETHER — instead of
+// one lane's box test and another's (much longer) leaf test taking turns in every iteration.
+// INSTANCES (a complex whose body is a node, CXF_INSTANCE: Translate / Rotate over a Bvh, hittable.rs:364-386 calling
+// hittable.rs:400-412): the walk maps the ray into the instance's frame exactly as the wrappers' hit arms do (f64: op by
+// op; f32: the composed rigid map), pushes REF_MARKER and descends into the sub-tree with the SAME running `closest`
+// (the arms pass t_min / t_max through; t is the same in every frame); popping the marker restores the world ray.  A
+// hit inside is reported as the leaf's synthesized complex (SceneView::leaf_by_rank), whose record make_hit_record
+// builds through the same wrapper chain.
+// INST: the instantiation that carries the instance arm (scenes without instances run the one without: the mapped
+// ray's registers cost the f32 reference-order kernel a third of its speed on the reference's default job otherwise).
+template <bool INST, typename R, bool STATS>
+RT_DEV void traverse_impl(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, uint32_t* stack,
+                          uint32_t stride, R& closest, uint32_t& best, Cnt<STATS>& cnt) {
   closest = Consts<R>::inf;
   best = REF_NONE;
   uint32_t cur = sc.root;
   if (cur == REF_NONE) return;
-  const Vec3<R> inv_d = inverse3(r.d);
-  const R a = sqrlen(r.d);
+  RayT<R> lr = r;  // the ray in the frame being walked (INST = false: always the world ray)
+  Vec3<R> inv_d = inverse3(r.d);
+  R a = sqrlen(r.d);
+  bool in_instance = false;
   uint32_t sp = 0;
-#if RT_TRAVERSE_PHASED
-  // Same per-lane visiting order, run in two wave phases: every lane first descends through inner nodes until it
-  // stands at a leaf (or has nothing left), then the lanes at a leaf run their leaf tests TOGETHER — instead of
-  // one lane's box test and another's (much longer) leaf test taking turns in every iteration.
   bool walking = true;
   for (;;) {
     while (walking && !(cur & REF_LEAF)) {
       cnt.template inc<ST_NODES>();
       Node<R> n = sc.nodes[cur];
       R lo = t_min, hi = closest;
-      if (slab_hit(n.lo, n.hi, r.o, inv_d, lo, hi)) {
+      if (slab_hit(n.lo, n.hi, lr.o, inv_d, lo, hi)) {
         stack[sp * stride] = n.right;
         ++sp;
         cur = n.left;
@@ -410,60 +417,80 @@ RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng
       }
     }
     if (!walking) break;
-    R t;
-    bool h;
-    if constexpr (sizeof(R) == 4)
-      h = leaf_t_unified(sc, cur, r, inv_d, a, t_min, closest, rng, t, cnt);
-    else if (ref_kind(cur) == LEAF_COMPLEX)
-      h = complex_t(sc, ref_index(cur), r, t_min, closest, rng, t, cnt);
-    else
-      h = prim_t(sc, cur, r, inv_d, a, t_min, closest, t, cnt);
-    // hittable.rs:405-411: the first record found is kept whatever its t (a NaN t from a NaN ray included — the
-    // reference returns it, and every later `right.t < left.t` is then false); a later one must be strictly closer.
-    // KNOWN GAP (NaN t only, never seen in any sweep): in the recursion a NaN-t record that is the first one found
-    // inside a RIGHT subtree becomes that subtree's t_max, so the rest of that subtree is discarded, and the
-    // subtree's answer (NaN) then loses against the left record; here `closest` stays finite across that subtree, so
-    // a later leaf of it with t < closest is still accepted.  The two agree whenever the NaN record is the walk's
-    // first record (handled above) or no NaN t arises at all (every finite ray against finite geometry).
-    if (h && (best == REF_NONE || t < closest)) {
-      closest = t;
-      best = cur;
-    }
-    if (sp == 0) break;
-    --sp;
-    cur = stack[sp * stride];
-  }
-#else
-  for (;;) {
-    if (!(cur & REF_LEAF)) {
-      cnt.template inc<ST_NODES>();
-      Node<R> n = sc.nodes[cur];
-      R lo = t_min, hi = closest;
-      if (slab_hit(n.lo, n.hi, r.o, inv_d, lo, hi)) {
-        stack[sp * stride] = n.right;
-        ++sp;
-        cur = n.left;
-        continue;
+    if (INST && cur == REF_MARKER) {  // the instance's sub-tree is done: back to the world's frame
+      lr = r;
+      inv_d = inverse3(r.d);
+      a = sqrlen(r.d);
+      in_instance = false;
+    } else if (INST && ref_kind(cur) == LEAF_COMPLEX && (sc.complexes[ref_index(cur)].flags & CXF_INSTANCE)) {
+      const Complex cx = sc.complexes[ref_index(cur)];
+      cnt.template inc<ST_TRANSLATE>(cx.n_translate);
+      cnt.template inc<ST_ROTATE>(cx.n_rotate);
+      if constexpr (sizeof(R) == 4) {
+        const ComplexXf<R>& xf = sc.complex_xf[ref_index(cur)];
+        lr.o = xf_point(xf.m_full, xf.b_full, r.o);
+        lr.d = xf_dir(xf.m_full, r.d);
+      } else {
+        for (uint32_t k = 0; k < cx.op_count; ++k) {  // hittable.rs:365, 375-377, outermost first
+          const Op<R> op = sc.ops[cx.op_first + k];
+          if (sc.op_tag[cx.op_first + k] == OP_TRANSLATE) {
+            lr.o = lr.o - Vec3<R>(op.d[0], op.d[1], op.d[2]);
+          } else {
+            const Quat<R> q{op.d[0], op.d[1], op.d[2], op.d[3]};
+            lr.o = qrotate(lr.o, q);
+            lr.d = qrotate(lr.d, q);
+          }
+        }
       }
+      inv_d = inverse3(lr.d);
+      a = sqrlen(lr.d);
+      in_instance = true;
+      stack[sp * stride] = REF_MARKER;
+      ++sp;
+      cur = cx.body;  // a node: the sub-tree's root, its box tested against the mapped ray like any other
+      continue;
     } else {
       R t;
       bool h;
-      if constexpr (sizeof(R) == 4)
-        h = leaf_t_unified(sc, cur, r, inv_d, a, t_min, closest, rng, t, cnt);
-      else if (ref_kind(cur) == LEAF_COMPLEX)
-        h = complex_t(sc, ref_index(cur), r, t_min, closest, rng, t, cnt);
+      uint32_t leaf = cur;
+      if (INST && in_instance) leaf = sc.leaf_by_rank[leaf_rank(sc, cur)];  // this leaf as a complex of its own (f32: or baked)
+      if constexpr (sizeof(R) == 4) {
+        // f32: a leaf of an instance is tested as every other f32 walk tests it — its synthesized complex (or baked
+        // sphere) against the WORLD ray — so that all f32 walks compute the same bits for it; the mapped ray only
+        // culls (the sub-tree's boxes).  The f64 walk below is literal: the primitive against the mapped ray.
+        if (INST && in_instance)
+          h = leaf_t_unified(sc, leaf, r, inverse3(r.d), sqrlen(r.d), t_min, closest, rng, t, cnt);
+        else
+          h = leaf_t_unified(sc, cur, lr, inv_d, a, t_min, closest, rng, t, cnt);
+      } else if (ref_kind(cur) == LEAF_COMPLEX)
+        h = complex_t(sc, ref_index(cur), lr, t_min, closest, rng, t, cnt);
       else
-        h = prim_t(sc, cur, r, inv_d, a, t_min, closest, t, cnt);
+        h = prim_t(sc, cur, lr, inv_d, a, t_min, closest, t, cnt);
+      // hittable.rs:405-411: the first record found is kept whatever its t (a NaN t from a NaN ray included — the
+      // reference returns it, and every later `right.t < left.t` is then false); a later one must be strictly closer.
+      // KNOWN GAP (NaN t only, never seen in any sweep): in the recursion a NaN-t record that is the first one found
+      // inside a RIGHT subtree becomes that subtree's t_max, so the rest of that subtree is discarded, and the
+      // subtree's answer (NaN) then loses against the left record; here `closest` stays finite across that subtree, so
+      // a later leaf of it with t < closest is still accepted.  The two agree whenever the NaN record is the walk's
+      // first record (handled above) or no NaN t arises at all (every finite ray against finite geometry).
       if (h && (best == REF_NONE || t < closest)) {
         closest = t;
-        best = cur;
+        best = leaf;
       }
     }
     if (sp == 0) break;
     --sp;
     cur = stack[sp * stride];
   }
-#endif
+}
+
+template <typename R, bool STATS>
+RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, uint32_t* stack,
+                     uint32_t stride, R& closest, uint32_t& best, Cnt<STATS>& cnt) {
+  if (sc.has_instances)  // wave-uniform (a kernel argument)
+    traverse_impl<true>(sc, r, t_min, rng, stack, stride, closest, best, cnt);
+  else
+    traverse_impl<false>(sc, r, t_min, rng, stack, stride, closest, best, cnt);
 }
 
 // ORDERED walk (f32 production path for scenes too large for the leaf list).
@@ -477,7 +504,7 @@ RT_DEV void traverse(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng
 // whose box entry is beyond the current closest, keep the bounds inclusive (next float above
 // `closest`) and break exact ties by the stored DFS rank — same winner as hittable.rs:400-412,
 // a fraction of the node visits.
-RT_DEV uint32_t leaf_rank(const SceneView<float>& sc, uint32_t ref) {
+template <typename R> RT_DEV uint32_t leaf_rank(const SceneView<R>& sc, uint32_t ref) {
   const uint32_t k = ref_kind(ref), i = ref_index(ref);
   if (k == LEAF_SPHERE) return sc.sphere_attr[i].rank;
   if (k == LEAF_MSPHERE) return sc.msphere_attr[i].rank;

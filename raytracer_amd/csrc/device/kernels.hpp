@@ -551,7 +551,11 @@ struct RenderArgs {
 // leaf-list scenes)
 constexpr int TRAV_REFERENCE = 0, TRAV_LINEAR = 1, TRAV_ORDERED = 2, TRAV_LEAVES = 3;
 
-template <typename R, bool STATS, bool EARLY_EXIT, int TRAV, bool NOISE = false>
+// INST (TRAV_REFERENCE only): -1 = the walk picks its instance / no-instance form at run time (SceneView::has_instances);
+// 0 / 1 = compiled for scenes without / with instances — the f32 product instantiation of the reference-order kernel is
+// launched that way, so that the kernel scenes without instances run (the reference's default scene among them) is the
+// one it was before instances existed
+template <typename R, bool STATS, bool EARLY_EXIT, int TRAV, bool NOISE = false, int INST = -1>
 __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : (sizeof(R) == 8 ? RT_RENDER_F64_MIN_WAVES : RT_RENDER_MIN_WAVES)) render_kernel(SceneView<R> sc, CameraView<R> cam, RenderArgs a,
                                                        R* __restrict__ accum, DeviceStats* stats) {
   constexpr bool LINEAR = TRAV == TRAV_LINEAR;
@@ -639,6 +643,10 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : (size
                            (uint32_t)BLOCK, cnt);
         t = walk.closest;
         best = walk.best;
+      } else if constexpr (INST == 0) {
+        traverse_impl<false>(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+      } else if constexpr (INST == 1) {
+        traverse_impl<true>(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
       } else {
         traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
       }

@@ -59,11 +59,17 @@ struct alignas(64) Node2 {
   float rbox[6];
   uint32_t left, right, flags, pad;
 };
+// flags & CXF_INSTANCE: `body` is not a leaf but the index of a NODE — the root of a sub-tree of its own (an instance:
+// Translate / Rotate over a Bvh, hittable.rs:81-91 over hittable.rs:93-98).  The reference-order walk enters it with
+// the ray mapped into its frame (traverse()); for every other walk rt_scene_create lists each leaf of the sub-tree
+// as a complex of its own (same wrapper chain, body = that leaf: "synthesized" complexes behind the caller's).
+constexpr uint32_t CXF_INSTANCE = 1u;
 struct Complex {
   uint32_t body, op_first, op_count, medium_pos;  // medium_pos = index of the MEDIUM op in the chain, or REF_NONE
   uint32_t material, object, n_rotate, n_translate;
-  uint32_t rank, pad[3];
+  uint32_t rank, flags, pad[2];
 };
+constexpr uint32_t REF_MARKER = REF_LEAF | (7u << 28);  // on a walk's stack: "back in the world's frame" (end of an instance)
 // The wrapper chain of a complex object composed on the host (in f64) into rigid maps
 // local = M * world + b.  `full` takes a world ray into the primitive's frame, `outer` into the
 // constant medium's frame (= full when there is no medium).  Used by the f32 kernels; the f64
@@ -137,6 +143,9 @@ template <typename R> struct SceneView {
   // n_leaf_list leaf references in BVH left-first DFS order, and how many records of the hot arrays a workgroup
   // stages in LDS for it (spheres incl. baked, cubes, complexes, ops).  n_leaf_list = 0: not eligible.
   const uint32_t* leaf_list;
+  const uint32_t* leaf_by_rank;  // every leaf of the scene by its left-first DFS rank, the leaves of instances as their
+                                 // synthesized complexes (f32 side: baked spheres where possible)
+  uint32_t has_instances;  // some complex carries CXF_INSTANCE (wave-uniform: the reference-order walk's instance arm)
   uint32_t n_leaf_list;
   uint32_t stage_spheres, stage_cubes, stage_complexes, stage_ops;
   uint32_t root;

@@ -100,7 +100,11 @@ struct Wrapper {
   Material material;  // Medium only: Isotropic(color), hittable.rs:148
 };
 struct Hittable {
-  enum Kind { Empty, Sphere, MovingSphere, Cube } kind = Empty;
+  // Bvh: Hittable::new_bvh over a slice of PRIMITIVES (hittable.rs:93-98, 159-206) as a value that Translate / Rotate may
+  // wrap — an INSTANCE (hittable.rs:81-91 hold a Box<Hittable> of any variant).  Its tree is built by the flattener
+  // with the axis stream instance_bvh_seed(bvh_seed, world index).
+  enum Kind { Empty, Sphere, MovingSphere, Cube, Bvh } kind = Empty;
+  std::shared_ptr<const std::vector<Hittable>> items;  // Bvh: the slice (bare primitives)
   Point a, b;  // Sphere: a = centre; MovingSphere: a = centre_start, b = centre_end; Cube: p0, p1
   double radius = 0, time_start = 0, time_end = 1;
   Material material;
@@ -114,7 +118,9 @@ struct Hittable {
   static Hittable new_constant_medium(Hittable boundary, double density, Color color);
   static Hittable new_rotate(Hittable h, double angle, Vector axis);
   static Hittable new_translate(Hittable h, Vector offset);  // hittable.rs:81-85 has no constructor (Q5)
+  static Hittable new_bvh(std::vector<Hittable> items);      // hittable.rs:159: the slice must hold >= 2 bare primitives
 };
+uint64_t instance_bvh_seed(uint64_t bvh_seed, uint32_t world_index);  // axis stream of an instance's own new_bvh
 
 struct Aabb {  // aabb.rs:6-10
   Point minimum, maximum;
@@ -164,7 +170,9 @@ SceneDef simple_light();                         // scenes.rs:133-175
 SceneDef cube_scene(const SceneOpts& o);         // scenes.rs:177-192
 SceneDef cornell_box();                          // BASELINE.json configs[1], [4]
 SceneDef bvh_stress(uint64_t seed, uint32_t n);  // BASELINE.json configs[3]
-SceneDef final_scene(const SceneOpts& o, bool perlin = false);  // BASELINE.json configs[2]; perlin: scene 11 (extension)
+SceneDef final_scene(const SceneOpts& o, bool perlin = false, bool instanced = false);  // BASELINE.json configs[2]; perlin: scene 11
+                                                                 // (extension); instanced: scene 16, the 1000 spheres as ONE
+                                                                 // Translate(Rotate(Bvh)) instance
 SceneDef scene_by_id(const SceneOpts& o);        // main.rs:117-124 (+ ids 6, 7, 8)
 
 // The flat scene: owns every array an rt_scene_desc points into.

@@ -246,6 +246,20 @@ Hittable Hittable::new_translate(Hittable h, Vector offset) {
   return h;
 }
 
+Hittable Hittable::new_bvh(std::vector<Hittable> items) {
+  if (items.size() < 2) throw std::runtime_error("Hittable::new_bvh: an instance needs a slice of two or more primitives");
+  for (const Hittable& it : items)
+    if (!it.wrappers.empty() || it.kind == Empty || it.kind == Bvh)
+      throw std::runtime_error("Hittable::new_bvh: the slice of an instance must hold bare primitives (sphere, moving sphere, cube)");
+  Hittable h;
+  h.kind = Bvh;
+  h.items = std::make_shared<const std::vector<Hittable>>(std::move(items));
+  return h;
+}
+uint64_t instance_bvh_seed(uint64_t bvh_seed, uint32_t world_index) {
+  return bvh_seed + 0x9E3779B97F4A7C15ull * (uint64_t)(world_index + 1u);
+}
+
 // ---- bounding boxes ----------------------------------------------------------------------
 Aabb surrounding_box(const Aabb& a, const Aabb& b) {
   Aabb r;
@@ -280,6 +294,16 @@ bool bounding_box(const Hittable& h, double t0, double t1, RotateBBox mode, Aabb
       Aabb b0{sub(moving_center(h, t0), rv), add(moving_center(h, t0), rv)};
       Aabb b1{sub(moving_center(h, t1), rv), add(moving_center(h, t1), rv)};
       box = surrounding_box(b0, b1);
+      break;
+    }
+    case Hittable::Bvh: {  // hittable.rs:457: the root's box = the union of the slice's boxes (min / max are exact: any order)
+      bool first = true;
+      for (const Hittable& it : *h.items) {
+        Aabb b;
+        if (!bounding_box(it, t0, t1, mode, &b)) return false;
+        box = first ? b : surrounding_box(box, b);
+        first = false;
+      }
       break;
     }
   }
@@ -558,14 +582,49 @@ struct Flattener {
         return RT_MAKE_LEAF(RT_LEAF_CUBE, i);
       }
       case Hittable::Empty:
+      case Hittable::Bvh:
         break;
     }
     throw std::runtime_error("flatten: Hittable::Empty inside a world of two or more objects");
   }
 
-  uint32_t add_object(const Hittable& h, uint32_t object) {
-    uint32_t body = add_primitive(h, object);
-    if (h.wrappers.empty()) return body;
+  // An instance's own tree (Hittable::new_bvh over its slice), appended to the scene's node arrays behind the nodes
+  // that exist so far (children still come after their parents); returns its root's node index.  The slice's
+  // primitives carry the instance's object id (HitRecord keeps what the outermost world-level object is).
+  uint32_t add_subtree(const Hittable& h, uint32_t object, uint64_t bvh_seed, RotateBBox mode) {
+    const std::vector<Hittable>& items = *h.items;
+    FlatBvh sub = new_bvh(items, 0.0, 1.0, instance_bvh_seed(bvh_seed, object), mode);
+    const uint32_t base = (uint32_t)fs.bvh.left.size();
+    std::vector<uint32_t> typed(items.size(), RT_REF_NONE);
+    auto fix = [&](uint32_t ref) -> uint32_t {
+      if (!(ref & RT_REF_LEAF)) return base + ref;
+      const uint32_t k = ref & ~RT_REF_LEAF;
+      if (typed[k] == RT_REF_NONE) typed[k] = add_primitive(items[k], object);
+      return typed[k];
+    };
+    for (size_t i = 0; i < sub.left.size(); ++i) {  // pre-order = DFS order: the slice is laid out in leaf order
+      const uint32_t l = fix(sub.left[i]), r = fix(sub.right[i]);
+      fs.bvh.left.push_back(l);
+      fs.bvh.right.push_back(r);
+    }
+    fs.bvh.box.insert(fs.bvh.box.end(), sub.box.begin(), sub.box.end());
+    fs.bvh.calls += sub.calls;
+    sub_height = std::max(sub_height, sub.height);
+    return base + sub.root;  // (>= 2 items: the root is a node)
+  }
+  uint32_t sub_height = 0;
+
+  uint32_t add_object(const Hittable& h, uint32_t object, uint64_t bvh_seed = 0, RotateBBox mode = RotateBBox::Correct) {
+    if (h.kind == Hittable::Bvh) {
+      for (const Wrapper& w : h.wrappers)
+        if (w.kind == Wrapper::Medium)
+          throw std::runtime_error("flatten: a constant medium around a Bvh is not representable (its boundary must be a primitive)");
+    }
+    uint32_t body = h.kind == Hittable::Bvh ? add_subtree(h, object, bvh_seed, mode) : add_primitive(h, object);
+    if (h.wrappers.empty()) {
+      if (h.kind == Hittable::Bvh) throw std::runtime_error("flatten: a bare Bvh inside a world (wrap it, or add its items to the world)");
+      return body;
+    }
     uint32_t me = (uint32_t)fs.complex_body.size();
     uint32_t medium_material = RT_REF_NONE;
     uint32_t first = (uint32_t)fs.op_tag.size();
@@ -596,22 +655,30 @@ FlatScene flatten(const SceneDef& def, uint64_t bvh_seed, RotateBBox mode) {
   fs.background = def.background;
   fs.n_objects = (uint32_t)def.world.size();
   fs.bvh = new_bvh(def.world, 0.0, 1.0, bvh_seed, mode);  // main.rs:125
-  Flattener fl{fs, {}};
+  Flattener fl{fs, 0, {}};
   // objects are laid out in BVH leaf (DFS) order so that siblings are neighbours in memory
   std::vector<uint32_t> typed(def.world.size(), RT_REF_NONE);
   auto leaf_ref = [&](uint32_t ref) -> uint32_t {
     uint32_t wi = ref & ~RT_REF_LEAF;
-    if (typed[wi] == RT_REF_NONE) typed[wi] = fl.add_object(def.world[wi], wi);
+    if (typed[wi] == RT_REF_NONE) typed[wi] = fl.add_object(def.world[wi], wi, bvh_seed, mode);
     return typed[wi];
   };
   if (fs.bvh.root != RT_REF_NONE && (fs.bvh.root & RT_REF_LEAF)) {
     const Hittable& only = def.world[0];
     fs.bvh.root = only.kind == Hittable::Empty ? RT_REF_NONE : leaf_ref(fs.bvh.root);
   }
-  for (size_t i = 0; i < fs.bvh.left.size(); ++i) {  // pre-order index order = DFS order, left before right
-    if (fs.bvh.left[i] & RT_REF_LEAF) fs.bvh.left[i] = leaf_ref(fs.bvh.left[i]);
-    if (fs.bvh.right[i] & RT_REF_LEAF) fs.bvh.right[i] = leaf_ref(fs.bvh.right[i]);
+  const size_t n_world_nodes = fs.bvh.left.size();  // (instances append their own trees behind these)
+  for (size_t i = 0; i < n_world_nodes; ++i) {  // pre-order index order = DFS order, left before right
+    if (fs.bvh.left[i] & RT_REF_LEAF) {
+      const uint32_t l = leaf_ref(fs.bvh.left[i]);  // (may grow the arrays: no reference into them across the call)
+      fs.bvh.left[i] = l;
+    }
+    if (fs.bvh.right[i] & RT_REF_LEAF) {
+      const uint32_t r = leaf_ref(fs.bvh.right[i]);
+      fs.bvh.right[i] = r;
+    }
   }
+  if (fl.sub_height) fs.bvh.height += 1 + fl.sub_height;  // an upper bound (rt_scene_create computes the exact depth)
 
   // main.rs:126-131
   const std::vector<Hittable>& l = def.lights;

@@ -210,7 +210,7 @@ SceneDef bvh_stress(uint64_t seed, uint32_t n) {
   return s;
 }
 
-SceneDef final_scene(const SceneOpts& o, bool perlin) {
+SceneDef final_scene(const SceneOpts& o, bool perlin, bool instanced) {
   SceneDef s;
   Stream r = scene_stream(o.scene_seed, 0);
   const Material ground = Material::new_lambertian(Color(0.48, 0.83, 0.53));
@@ -242,12 +242,20 @@ SceneDef final_scene(const SceneOpts& o, bool perlin) {
       Material::new_lambertian_with_texture(perlin ? Texture::new_noise(Texture::make_noise_table(noise_stream), 0.1)
                                                    : Texture::new_checker_color(Color(0.2, 0.3, 0.1), Color(0.9, 0.9, 0.9)))));
   const Material white = Material::new_lambertian(Color(0.73, 0.73, 0.73));
+  std::vector<Hittable> cluster;
   for (int j = 0; j < 1000; ++j) {
     const double x = r.range(0.0, 165.0), y = r.range(0.0, 165.0), z = r.range(0.0, 165.0);
-    s.world.push_back(Hittable::new_translate(
-        Hittable::new_rotate(Hittable::new_sphere(Point(x, y, z), 10.0, white), to_radians(-15.0), Vector(0.0, 1.0, 0.0)),
-        Vector(-100.0, 270.0, 395.0)));
+    if (instanced)
+      cluster.push_back(Hittable::new_sphere(Point(x, y, z), 10.0, white));
+    else
+      s.world.push_back(Hittable::new_translate(
+          Hittable::new_rotate(Hittable::new_sphere(Point(x, y, z), 10.0, white), to_radians(-15.0), Vector(0.0, 1.0, 0.0)),
+          Vector(-100.0, 270.0, 395.0)));
   }
+  if (instanced)  // the book's structure: one box of spheres, turned and moved as a whole
+    s.world.push_back(Hittable::new_translate(
+        Hittable::new_rotate(Hittable::new_bvh(std::move(cluster)), to_radians(-15.0), Vector(0.0, 1.0, 0.0)),
+        Vector(-100.0, 270.0, 395.0)));
   s.cam = CameraSpec{Point(478.0, 278.0, -600.0), Point(278.0, 278.0, 0.0), Vector(0.0, 1.0, 0.0), 40.0, 0.0, 10.0, 0.0, 1.0};
   s.background = Color(0.0, 0.0, 0.0);
   s.rotate_bbox = RotateBBox::Correct;
@@ -376,6 +384,7 @@ SceneDef scene_by_id(const SceneOpts& o) {
     case 13: return area_light_plate();
     case 14: return random_scene_stdrng(o.scene_seed);
     case 15: return area_light_list();
+    case 16: return final_scene(o, false, true);
     default: return small_scene();  // main.rs:123
   }
 }

@@ -135,12 +135,20 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
     return hipGetLastError();
   }
   if constexpr (!F64) {
-    if (stats)
-      RT_LAUNCH((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
-                         accum, dstats);
-    else
-      RT_LAUNCH((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_REFERENCE>), grid, block, lds, st, sc, cam, a,
-                         accum, dstats);
+    if (sc.has_instances) {
+      if (stats)
+        RT_LAUNCH((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE, false, 1>), grid, block, lds, st, sc, cam, a,
+                  accum, dstats);
+      else
+        RT_LAUNCH((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_REFERENCE, false, 1>), grid, block, lds, st, sc, cam, a,
+                  accum, dstats);
+    } else if (stats) {
+      RT_LAUNCH((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE, false, 0>), grid, block, lds, st, sc, cam, a,
+                accum, dstats);
+    } else {
+      RT_LAUNCH((render_kernel<RT_REAL, false, RT_EARLY_EXIT, TRAV_REFERENCE, false, 0>), grid, block, lds, st, sc, cam, a,
+                accum, dstats);
+    }
   }
   return hipGetLastError();
 }

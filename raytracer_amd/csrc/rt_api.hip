@@ -133,7 +133,8 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
   // record instead of the complex (one 16-byte fetch and no rigid map per test: final_scene wraps each of its 1000
   // small spheres this way, where the reference has one Translate(Rotate(Bvh)) instance), the f64 audit side keeps
   // walking the literal wrapper chain (hittable.rs:364-386) and only holds the record for rt_primary_hits' audit.
-  std::vector<uint32_t> baked(d.n_complex, RT_REF_NONE);  // complex index -> index of its baked sphere record
+  const uint32_t n_complex = (uint32_t)complexes.size();  // the caller's, then the synthesized ones (instances' leaves)
+  std::vector<uint32_t> baked(n_complex, RT_REF_NONE);  // complex index -> index of its baked sphere record
   std::vector<std::array<double, 4>> baked_sphere;
   std::vector<Attr> baked_attr;
   {
@@ -143,8 +144,9 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
       if (d.tex_tag[i] == RT_TEX_CHECKER) tex_uv0[i] = tex_uv0[d.tex_odd[i]] | tex_uv0[d.tex_even[i]];
     }
     static const bool no_bake = getenv("RT_NO_BAKE") != nullptr;  // A/B switch
-    for (uint32_t i = 0; i < d.n_complex && !no_bake; ++i) {
+    for (uint32_t i = 0; i < n_complex && !no_bake; ++i) {
       const Complex& cx = complexes[i];
+      if ((cx.flags & CXF_INSTANCE) || facts.rank_complex[i] == RT_REF_NONE) continue;  // (a sub-tree; not in the tree)
       if (cx.medium_pos != REF_NONE || RT_REF_KIND(cx.body) != RT_LEAF_SPHERE) continue;
       const uint32_t bi = RT_REF_INDEX(cx.body), m = d.sphere_material[bi];
       if (d.mat_texture[m] < d.n_textures && tex_uv0[d.mat_texture[m]]) continue;
@@ -190,7 +192,9 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
   // the reference's tree into Node2 form instead.
   std::vector<Node2> nodes2;
   if constexpr (sizeof(R) == 4) {
-    const bool own_tree = getenv("RT_ORDERED_REFERENCE_TREE") == nullptr;
+    bool has_inst = false;
+    for (const Complex& c : complexes) has_inst |= (c.flags & CXF_INSTANCE) != 0;
+    const bool own_tree = getenv("RT_ORDERED_REFERENCE_TREE") == nullptr || has_inst;  // (the mirror has no instance arm)
     if (facts.conservative && facts.leaf_refs.size() >= 2 && own_tree) {
       const uint32_t n_leaves = (uint32_t)facts.leaf_refs.size();
       std::vector<uint32_t> refs(facts.leaf_refs);
@@ -303,8 +307,8 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
     for (int k = 0; k < 3; ++k) texs[i].color[k] = conv<R>(d.tex_color[3 * (size_t)i + k]);
   }
   // compose each complex object's wrapper chain into rigid maps (f64 on the host)
-  std::vector<ComplexXf<R>> xfs(d.n_complex);
-  for (uint32_t i = 0; i < d.n_complex; ++i) {
+  std::vector<ComplexXf<R>> xfs(n_complex);
+  for (uint32_t i = 0; i < n_complex; ++i) {
     double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, b[3] = {0, 0, 0};
     double Mo[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, bo[3] = {0, 0, 0};
     double nid = 0.0;
@@ -445,7 +449,12 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
       complexes.size() <= STAGE_MAX_COMPLEXES && ops.size() <= STAGE_MAX_OPS)
     for (uint32_t ref : linear) leaf_list.push_back(f32_ref(ref));
   UP(leaf_list, leaf_list)
+  std::vector<uint32_t> leaf_by_rank(facts.leaf_refs);
+  for (uint32_t& r : leaf_by_rank) r = f32_ref(r);
+  UP(leaf_by_rank, leaf_by_rank)
 #undef UP
+  s.view.has_instances = 0;
+  for (const Complex& c : complexes) s.view.has_instances |= (c.flags & CXF_INSTANCE) ? 1u : 0u;
   s.view.n_leaf_list = (uint32_t)leaf_list.size();
   s.view.stage_spheres = (uint32_t)spheres.size();
   s.view.stage_cubes = (uint32_t)cubes.size();
@@ -508,53 +517,52 @@ bool is_valid_leaf(uint32_t ref, const rt_scene_desc& d) {
   return RT_REF_KIND(ref) == RT_LEAF_COMPLEX && RT_REF_INDEX(ref) < d.n_complex;
 }
 
-// Conservative world-space bounds of a leaf.  A moving sphere is bounded over its own
-// [time_start, time_end] only; *t_lo / *t_hi are narrowed to the ray times for which the bounds hold.
-bool leaf_world_bounds(const rt_scene_desc& d, const std::vector<Complex>& complexes, uint32_t ref, double lo[3],
-                       double hi[3], double* t_lo = nullptr, double* t_hi = nullptr) {
-  auto prim_box = [&](uint32_t r, double plo[3], double phi[3]) -> bool {
-    const uint32_t k = RT_REF_KIND(r), i = RT_REF_INDEX(r);
-    if (k == RT_LEAF_SPHERE) {
-      const double* s = d.sphere + 4 * (size_t)i;
-      for (int c = 0; c < 3; ++c) {
-        plo[c] = s[c] - std::fabs(s[3]);
-        phi[c] = s[c] + std::fabs(s[3]);
-      }
-      return true;
+// Bounds of a bare primitive in its own frame.  A moving sphere is bounded over its own [time_start, time_end] only;
+// *t_lo / *t_hi are narrowed to the ray times for which the bounds hold.
+bool prim_local_box(const rt_scene_desc& d, uint32_t r, double plo[3], double phi[3], double* t_lo = nullptr,
+                    double* t_hi = nullptr) {
+  const uint32_t k = RT_REF_KIND(r), i = RT_REF_INDEX(r);
+  if (k == RT_LEAF_SPHERE) {
+    const double* s = d.sphere + 4 * (size_t)i;
+    for (int c = 0; c < 3; ++c) {
+      plo[c] = s[c] - std::fabs(s[3]);
+      phi[c] = s[c] + std::fabs(s[3]);
     }
-    if (k == RT_LEAF_CUBE) {
-      const double* q = d.cube + 6 * (size_t)i;
-      for (int c = 0; c < 3; ++c) {
-        plo[c] = std::fmin(q[c], q[3 + c]);
-        phi[c] = std::fmax(q[c], q[3 + c]);
-      }
-      return true;
+    return true;
+  }
+  if (k == RT_LEAF_CUBE) {
+    const double* q = d.cube + 6 * (size_t)i;
+    for (int c = 0; c < 3; ++c) {
+      plo[c] = std::fmin(q[c], q[3 + c]);
+      phi[c] = std::fmax(q[c], q[3 + c]);
     }
-    if (k == RT_LEAF_MSPHERE) {  // centre moves linearly between c0 (time_start) and c1 (time_end)
-      const double* m = d.msphere + 9 * (size_t)i;
-      const double r = std::fabs(m[6]);
-      if (!(m[7] < m[8])) return false;
-      for (int c = 0; c < 3; ++c) {
-        plo[c] = std::fmin(m[c], m[3 + c]) - r;
-        phi[c] = std::fmax(m[c], m[3 + c]) + r;
-      }
-      if (t_lo) *t_lo = std::fmax(*t_lo, m[7]);
-      if (t_hi) *t_hi = std::fmin(*t_hi, m[8]);
-      return true;
+    return true;
+  }
+  if (k == RT_LEAF_MSPHERE) {  // centre moves linearly between c0 (time_start) and c1 (time_end)
+    const double* m = d.msphere + 9 * (size_t)i;
+    const double r_ = std::fabs(m[6]);
+    if (!(m[7] < m[8])) return false;
+    for (int c = 0; c < 3; ++c) {
+      plo[c] = std::fmin(m[c], m[3 + c]) - r_;
+      phi[c] = std::fmax(m[c], m[3 + c]) + r_;
     }
-    return false;
-  };
-  if (RT_REF_KIND(ref) != RT_LEAF_COMPLEX) return prim_box(ref, lo, hi);
-  const Complex& cx = complexes[RT_REF_INDEX(ref)];
-  double plo[3], phi[3];
-  if (!prim_box(cx.body, plo, phi)) return false;
+    if (t_lo) *t_lo = std::fmax(*t_lo, m[7]);
+    if (t_hi) *t_hi = std::fmin(*t_hi, m[8]);
+    return true;
+  }
+  return false;
+}
+
+// The box [plo, phi] of a complex's body frame, seen from outside its wrapper chain: the eight corners taken back out
+// through the wrappers, innermost first — Rotate by q* (hittable.rs:379-383), Translate by +offset — and bounded.
+void chain_bounds(const rt_scene_desc& d, const Complex& cx, const double plo[3], const double phi[3], double lo[3],
+                  double hi[3]) {
   for (int c = 0; c < 3; ++c) {
     lo[c] = INFINITY;
     hi[c] = -INFINITY;
   }
   for (int corner = 0; corner < 8; ++corner) {
     double p[3] = {(corner & 1) ? phi[0] : plo[0], (corner & 2) ? phi[1] : plo[1], (corner & 4) ? phi[2] : plo[2]};
-    // undo the wrappers innermost first: Rotate by q* (hittable.rs:379-383), Translate by +offset
     for (uint32_t k = cx.op_count; k-- > 0;) {
       const uint32_t o = cx.op_first + k;
       const double* q = d.op_data + 4 * (size_t)o;
@@ -572,6 +580,16 @@ bool leaf_world_bounds(const rt_scene_desc& d, const std::vector<Complex>& compl
       hi[c] = std::fmax(hi[c], p[c]);
     }
   }
+}
+
+// Conservative world-space bounds of a leaf (for a complex whose body is a primitive).
+bool leaf_world_bounds(const rt_scene_desc& d, const std::vector<Complex>& complexes, uint32_t ref, double lo[3],
+                       double hi[3], double* t_lo = nullptr, double* t_hi = nullptr) {
+  if (RT_REF_KIND(ref) != RT_LEAF_COMPLEX) return prim_local_box(d, ref, lo, hi, t_lo, t_hi);
+  const Complex& cx = complexes[RT_REF_INDEX(ref)];
+  double plo[3], phi[3];
+  if ((cx.flags & CXF_INSTANCE) || !prim_local_box(d, cx.body, plo, phi, t_lo, t_hi)) return false;
+  chain_bounds(d, cx, plo, phi, lo, hi);
   return true;
 }
 
@@ -732,10 +750,18 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
 
   std::vector<Complex> complexes(d->n_complex);
   for (uint32_t i = 0; i < d->n_complex; ++i) {
-    if (!is_simple_leaf(d->complex_body[i], *d))
-      return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: complex %u body must be a sphere / moving sphere / cube leaf", i);
+    // a body that is a node index (no RT_REF_LEAF): an INSTANCE, the wrappers over a sub-tree (hittable.rs:81-91 hold
+    // a Box<Hittable> of any variant: here a Bvh)
+    const bool instance = d->complex_body[i] != RT_REF_NONE && !(d->complex_body[i] & RT_REF_LEAF);
+    if (instance) {
+      NEED(d->complex_body[i] < d->n_nodes, "complex body: node index out of range");
+    } else if (!is_simple_leaf(d->complex_body[i], *d)) {
+      return fail(RT_ERR_UNSUPPORTED,
+                  "rt_scene_create: complex %u body must be a sphere / moving sphere / cube leaf or a node (a sub-tree)", i);
+    }
     NEED((uint64_t)d->complex_op_first[i] + d->complex_op_count[i] <= d->n_ops, "complex op range out of bounds");
     Complex c{};
+    c.flags = instance ? CXF_INSTANCE : 0u;
     c.body = d->complex_body[i];
     c.op_first = d->complex_op_first[i];
     c.op_count = d->complex_op_count[i];
@@ -756,6 +782,8 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
       if (tag == RT_OP_MEDIUM) {
         if (c.medium_pos != REF_NONE)
           return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: complex %u nests two constant media", i);
+        if (instance)
+          return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: complex %u: a constant medium whose boundary is a sub-tree", i);
         c.medium_pos = k;
       }
     }
@@ -764,12 +792,22 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
   }
 
   // BVH: pre-order (children after parents) makes it acyclic; compute its height bottom-up.
+  // (height = stack entries a walk below this node may hold: an instance leaf costs its marker plus its sub-tree)
   std::vector<uint32_t> height(d->n_nodes, 0);
+  auto instance_of = [&](uint32_t ref) -> const Complex* {
+    if (ref == RT_REF_NONE || !(ref & RT_REF_LEAF) || RT_REF_KIND(ref) != RT_LEAF_COMPLEX) return nullptr;
+    const Complex& c = complexes[RT_REF_INDEX(ref)];
+    return (c.flags & CXF_INSTANCE) ? &c : nullptr;
+  };
   for (uint32_t ii = d->n_nodes; ii-- > 0;) {
     uint32_t h = 0;
     for (uint32_t ref : {d->node_left[ii], d->node_right[ii]}) {
       if (ref & RT_REF_LEAF) {
         NEED(is_valid_leaf(ref, *d), "node child is not a valid leaf");
+        if (const Complex* inst = instance_of(ref)) {
+          NEED(inst->body > ii, "an instance's sub-tree must come after the node that holds the instance (pre-order)");
+          h = std::max(h, 1u + height[inst->body]);
+        }
       } else {
         NEED(ref < d->n_nodes && ref > ii, "node child must be a later node (pre-order)");
         h = std::max(h, height[ref]);
@@ -781,6 +819,7 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
   if (d->root == RT_REF_NONE) {
   } else if (d->root & RT_REF_LEAF) {
     NEED(is_valid_leaf(d->root, *d), "root is not a valid leaf");
+    if (const Complex* inst = instance_of(d->root)) tree_height = 1u + height[inst->body];
   } else {
     NEED(d->root < d->n_nodes, "root out of range");
     tree_height = height[d->root];
@@ -802,9 +841,10 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
   facts.rank_complex.assign(d->n_complex, RT_REF_NONE);
   if (d->root != RT_REF_NONE) {
     struct Todo {
-      uint32_t ref, parent;
+      uint32_t ref, parent;  // parent: the node whose box must bound this entry (RT_REF_NONE: none to check)
+      uint32_t inst;         // the instance (complex index) whose sub-tree this entry belongs to, or RT_REF_NONE
     };
-    std::vector<Todo> todo{{d->root, RT_REF_NONE}};
+    std::vector<Todo> todo{{d->root, RT_REF_NONE, RT_REF_NONE}};
     auto inside = [&](const double lo[3], const double hi[3], uint32_t parent) {
       if (parent == RT_REF_NONE) return true;
       const double* nb = d->node_box + 6 * (size_t)parent;
@@ -814,51 +854,88 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
       }
       return true;
     };
+    std::vector<uint8_t> seen(d->n_nodes, 0);
     uint32_t nodes_reached = 0;
     while (!todo.empty()) {
       Todo cur = todo.back();
       todo.pop_back();
       if (!(cur.ref & RT_REF_LEAF)) {
+        if (seen[cur.ref]) return fail(RT_ERR_BAD_ARG, "rt_scene_create: node %u is referenced more than once", cur.ref);
+        seen[cur.ref] = 1;
         ++nodes_reached;
         const double* nb = d->node_box + 6 * (size_t)cur.ref;
         if (!inside(nb, nb + 3, cur.parent)) facts.conservative = false;
-        todo.push_back({d->node_right[cur.ref], cur.ref});
-        todo.push_back({d->node_left[cur.ref], cur.ref});
+        todo.push_back({d->node_right[cur.ref], cur.ref, cur.inst});
+        todo.push_back({d->node_left[cur.ref], cur.ref, cur.inst});
         continue;
       }
-      const uint32_t rank = (uint32_t)facts.leaf_refs.size();
-      facts.leaf_refs.push_back(cur.ref);
       const uint32_t k = RT_REF_KIND(cur.ref), i = RT_REF_INDEX(cur.ref);
+      if (k == RT_LEAF_COMPLEX && (complexes[i].flags & CXF_INSTANCE)) {
+        // An instance: its sub-tree's leaves take their place in the DFS order here.  Its box in the parent's frame =
+        // the sub-tree root's box through the wrappers (what hittable.rs:436-456 computes from the child's box).
+        if (cur.inst != RT_REF_NONE)
+          return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: complex %u: an instance inside an instance", i);
+        if (facts.rank_complex[i] != RT_REF_NONE)
+          return fail(RT_ERR_BAD_ARG, "rt_scene_create: a leaf is referenced by more than one node");
+        facts.rank_complex[i] = (uint32_t)facts.leaf_refs.size();  // (rank of its first leaf: marks it as placed)
+        const double* rb = d->node_box + 6 * (size_t)complexes[i].body;
+        double lo[3], hi[3];
+        chain_bounds(*d, complexes[i], rb, rb + 3, lo, hi);
+        if (!inside(lo, hi, cur.parent)) facts.conservative = false;
+        todo.push_back({complexes[i].body, RT_REF_NONE, i});
+        continue;
+      }
+      uint32_t leaf = cur.ref;
+      if (cur.inst != RT_REF_NONE) {
+        // a leaf of an instance's sub-tree: for every walk but the reference-order one it is a complex of its own —
+        // the instance's wrapper chain around this primitive — appended behind the caller's complexes
+        if (k == RT_LEAF_COMPLEX)
+          return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: an instance's sub-tree must hold bare primitives (complex %u inside complex %u)",
+                      i, cur.inst);
+        double plo[3], phi[3];
+        if (!prim_local_box(*d, cur.ref, plo, phi, &facts.t_lo, &facts.t_hi) || !inside(plo, phi, cur.parent)) facts.conservative = false;
+        Complex syn = complexes[cur.inst];
+        syn.flags = 0;
+        syn.body = cur.ref;
+        syn.rank = (uint32_t)facts.leaf_refs.size();
+        leaf = RT_MAKE_LEAF(RT_LEAF_COMPLEX, (uint32_t)complexes.size());
+        complexes.push_back(syn);
+        facts.rank_complex.push_back(RT_REF_NONE);
+      }
+      const uint32_t rank = (uint32_t)facts.leaf_refs.size();
+      facts.leaf_refs.push_back(leaf);
       std::vector<uint32_t>& ranks = k == RT_LEAF_SPHERE ? facts.rank_sphere
                                      : k == RT_LEAF_MSPHERE ? facts.rank_msphere
                                      : k == RT_LEAF_CUBE ? facts.rank_cube : facts.rank_complex;
       if (ranks[i] != RT_REF_NONE)
         return fail(RT_ERR_BAD_ARG, "rt_scene_create: a leaf is referenced by more than one node");
       ranks[i] = rank;
+      if (leaf != cur.ref) facts.rank_complex[RT_REF_INDEX(leaf)] = rank;
       double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-      if (!leaf_world_bounds(*d, complexes, cur.ref, lo, hi, &facts.t_lo, &facts.t_hi)) {
+      if (!leaf_world_bounds(*d, complexes, leaf, lo, hi, &facts.t_lo, &facts.t_hi)) {
         facts.conservative = false;
-      } else if (!inside(lo, hi, cur.parent)) {
+      } else if (cur.inst == RT_REF_NONE && !inside(lo, hi, cur.parent)) {
         facts.conservative = false;
       }
       // The f32 kernels map the ray into a wrapped object's frame with rounded maps: give such a
       // leaf's culling box a margin well above that rounding (culling only, never a hit test).
+      const uint32_t lk = RT_REF_KIND(leaf);
       for (int c = 0; c < 3; ++c) {
-        const double pad = k == RT_LEAF_COMPLEX ? 4e-6 * (std::fabs(lo[c]) + std::fabs(hi[c]) + 1.0) : 0.0;
+        const double pad = lk == RT_LEAF_COMPLEX ? 4e-6 * (std::fabs(lo[c]) + std::fabs(hi[c]) + 1.0) : 0.0;
         lo[c] -= pad;
         hi[c] += pad;
       }
       for (int c = 0; c < 3; ++c) facts.leaf_box.push_back(conv_down(lo[c]));
       for (int c = 0; c < 3; ++c) facts.leaf_box.push_back(conv_up(hi[c]));
       if (k == RT_LEAF_MSPHERE) facts.linear_ok = false;
-      if (k == RT_LEAF_COMPLEX) {
-        const Complex& cx = complexes[i];
+      if (lk == RT_LEAF_COMPLEX) {
+        const Complex& cx = complexes[RT_REF_INDEX(leaf)];
         if (RT_REF_KIND(cx.body) == RT_LEAF_MSPHERE) facts.linear_ok = false;
         if (cx.medium_pos != REF_NONE && cx.medium_pos != 0) facts.linear_ok = false;  // records keep media outermost
       }
     }
-    // every node must hang below the root (pre-order indices make a node reachable at most once): an orphan node's
-    // leaves would have no DFS rank, and nothing the reference builds (hittable.rs:159-206) has one
+    // every node must hang below the root, directly or through an instance: an orphan node's leaves would have no DFS
+    // rank, and nothing the reference builds (hittable.rs:159-206) has one
     if (nodes_reached != d->n_nodes)
       return fail(RT_ERR_BAD_ARG, "rt_scene_create: %u of %u nodes are not reachable from the root", d->n_nodes - nodes_reached,
                   d->n_nodes);
@@ -868,7 +945,7 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
   if (!facts.conservative || facts.leaf_refs.size() > LIN_MAX_LEAVES) facts.linear_ok = false;
   std::vector<uint32_t> linear;
   if (facts.linear_ok) linear = facts.leaf_refs;
-  for (uint32_t i = 0; i < d->n_complex; ++i) complexes[i].rank = facts.rank_complex[i];
+  for (size_t i = 0; i < complexes.size(); ++i) complexes[i].rank = facts.rank_complex[i];
 
   // (the description is validated in full before the first HIP call: a bad scene is RT_ERR_BAD_ARG with or without a GPU)
   int ndev = 0;

@@ -33,6 +33,8 @@ SCENES = {
     # random_scene with its geometry from StdRng::seed_from_u64(5) (parity unpinned: tests/test_stdrng.py)
     "random_scene_stdrng": (14, 16.0 / 9.0, 0, 50),
     "area_light_list": (15, 1.0, 0, 8),  # the box light inside a lights List (with a sphere lamp and a non-emitting bead)
+    # final_scene with its 1000 small spheres as ONE Translate(Rotate(Bvh)) instance (hittable.rs:81-91 over a Bvh)
+    "final_scene_instanced": (16, 1.0, 0, 50),
 }
 
 

@@ -9,7 +9,8 @@ for every scene at 64 px wide with fixed seeds (SURVEY.md section 8c "golden dat
 These are DATA produced by this repository's own oracle (the reference is Rust and cannot run
 here); they freeze the oracle, so an unintended change to it — or to the draw-stream conventions
 the HIP kernels share with it — fails tests/test_goldens.py on the CPU and on the GPU.
-Regenerate deliberately with:  python tests/golden/make_oracle_goldens.py
+Add the vectors of scenes that have none yet with:  python tests/golden/make_oracle_goldens.py
+(the scenes already in the file are kept byte for byte); regenerate everything deliberately with --all.
 """
 import os
 import sys
@@ -35,8 +36,14 @@ def scene_args(name):
 def main():
     import raytracer_amd as R
     earth = R.load_earthmap()
+    path = os.path.join(HERE, "oracle_goldens.npz")
     out = {}
+    if os.path.exists(path) and "--all" not in sys.argv:  # additive by default: scenes already frozen stay as they are
+        with np.load(path) as old:
+            out = {k: old[k] for k in old.files}
     for name in SCENES:
+        if f"{name}/root" in out:
+            continue
         sid, asp, n, depth = scene_args(name)
         orc = O.OracleScene(sid, asp, n=n, texels=earth)
         h = R.image_height(W, asp)
@@ -54,7 +61,6 @@ def main():
         out[f"{name}/image_sum"] = img
         out[f"{name}/counters"] = np.array([cnt[k] for k in O.COUNTER_FIELDS], dtype=np.uint64)
         print(name, "nodes", len(left), "rays", cnt["rays"])
-    path = os.path.join(HERE, "oracle_goldens.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 

@@ -64,7 +64,7 @@ def lib(name="liboracle.so"):
     """liboracle.so: the checker (counts its work, -O2, no fp contraction).  liboracle_nocount.so: the same
     sources at -O3 without the work counters, for bench.py's timed CPU baseline only."""
     if name not in _libs:
-        path = os.path.join(_ROOT, "oracle", name)
+        path = name if os.path.isabs(name) else os.path.join(_ROOT, "oracle", name)  # (absolute: a build made elsewhere)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
         L = C.CDLL(path)

@@ -113,6 +113,84 @@ def test_scene_create_validates_before_touching_the_device():
     assert rc == F.RT_ERR_BAD_ARG and ("reachable" in msg or "more than one" in msg), msg
 
 
+def test_instances_are_validated_before_touching_the_device():
+    """ABI 3: a complex whose body is a NODE is an instance — Translate / Rotate over a sub-tree (hittable.rs:81-91 over a
+    Bvh).  What the flat format cannot express is refused with RT_ERR_UNSUPPORTED, malformed references with
+    RT_ERR_BAD_ARG, all before any HIP call."""
+    from raytracer_amd import _ffi as F
+    import raytracer_amd as R
+    hs = R.HostScene("final_scene_instanced", 1.0)
+    d0 = hs.desc
+    inst = [i for i in range(d0.n_complex) if not (d0.complex_body[i] & 0x80000000)]
+    assert len(inst) == 1 and d0.complex_op_count[inst[0]] == 2
+    k = inst[0]
+    assert d0.n_nodes == 409 + 999 and d0.complex_body[k] == 409  # the sub-tree's nodes follow the world's
+    out = C.c_void_p()
+
+    def attempt(mutate):
+        d = F.RtSceneDesc()
+        C.memmove(C.byref(d), C.byref(d0), C.sizeof(d))
+        keep = mutate(d)
+        rc = F.hip.rt_scene_create(0, C.byref(d), C.byref(out))
+        if rc == F.RT_OK:
+            F.hip.rt_scene_destroy(out)
+        return rc, F.hip.rt_last_error().decode(), keep
+
+    def arr(d, field, n, dtype, ptype):
+        a = np.ctypeslib.as_array(getattr(d, field), shape=(n,)).view(dtype).copy()
+        setattr(d, field, a.ctypes.data_as(ptype))
+        return a
+
+    rc, msg, _ = attempt(lambda d: None)   # as built: accepted by validation
+    assert rc in (F.RT_OK, F.RT_ERR_HIP), msg
+
+    def medium_over_subtree(d):
+        tags = arr(d, "op_tag", d.n_ops, np.uint8, F._u8p)
+        tags[d.complex_op_first[k]] = 2  # RT_OP_MEDIUM
+        return tags
+    rc, msg, _ = attempt(medium_over_subtree)
+    assert rc == F.RT_ERR_UNSUPPORTED and "medium" in msg, msg
+
+    def body_out_of_range(d):
+        body = arr(d, "complex_body", d.n_complex, np.uint32, F._u32p)
+        body[k] = d.n_nodes
+        return body
+    rc, msg, _ = attempt(body_out_of_range)
+    assert rc == F.RT_ERR_BAD_ARG and "node index" in msg, msg
+
+    def body_before_its_holder(d):  # the sub-tree must come after the node that holds the instance (acyclic by construction)
+        body = arr(d, "complex_body", d.n_complex, np.uint32, F._u32p)
+        body[k] = 0
+        return body
+    rc, msg, _ = attempt(body_before_its_holder)
+    assert rc == F.RT_ERR_BAD_ARG, msg
+
+    def complex_inside_the_subtree(d):  # a wrapped primitive (or another instance) below an instance: not representable
+        left = arr(d, "node_left", d.n_nodes, np.uint32, F._u32p)
+        right = arr(d, "node_right", d.n_nodes, np.uint32, F._u32p)
+        other = [i for i in range(d.n_complex) if i != k][0]
+        ref = 0x80000000 | (3 << 28) | other
+        for a in (left, right):   # unhook it from the world's tree, hang it into the sub-tree
+            for i in range(409):
+                if a[i] == ref:
+                    a[i] = left[408] if a is right else right[408]
+        # (simplest legal-looking mutation: make a sub-tree leaf the instance itself -> an instance inside an instance)
+        left[d.n_nodes - 1] = 0x80000000 | (3 << 28) | k
+        return left, right
+    rc, msg, _ = attempt(complex_inside_the_subtree)
+    assert rc in (F.RT_ERR_UNSUPPORTED, F.RT_ERR_BAD_ARG), msg
+
+    def second_reference_to_the_subtree(d):  # two parents for one node
+        right = arr(d, "node_right", d.n_nodes, np.uint32, F._u32p)
+        for i in range(409):
+            if not (right[i] & 0x80000000):
+                right[i] = 409 + 5 if 409 + 5 > i else right[i]
+                break
+        return right
+    rc, msg, _ = attempt(second_reference_to_the_subtree)
+    assert rc == F.RT_ERR_BAD_ARG, msg
+
+
 def test_tree_height_limit_is_checked_at_create_time():
     """RT_MAX_BVH_HEIGHT = 63: what the LDS stack of the reference-order kernels holds."""
     from desc_util import chain_desc
@@ -236,7 +314,7 @@ def test_texture_file_side_channel(tmp_path):
     (tmp_path / "png.ppm").write_bytes(b"\x89PNG\r\n" + b"\0" * 64)
     with pytest.raises(F.RtError, match="neither a JPEG nor a binary PPM"):
         R.texture_from_file(str(tmp_path / "png.ppm"))
-    for sid in (2, 4, 8, 11):  # every scene that calls Texture::new_image
+    for sid in (2, 4, 8, 11, 16):  # every scene that calls Texture::new_image
         o = F.RthSceneOpts()
         o.scene_id, o.rotate_bbox, o.aspect_ratio, o.scene_seed, o.bvh_seed = sid, -1, 1.5, 5, 7
         h = C.c_void_p()

@@ -69,7 +69,9 @@ def test_primary_hits_f32(name, w, earthmap):
         dn = np.abs(gn[hit] - on[hit]).max(axis=-1)
         print(f"{name} w={w} fast={fast}: re-decided {redecided}/{gid.size}; t rel err max {rel_t.max() if rel_t.size else 0:.3g}; "
               f"normal abs err max {dn.max() if dn.size else 0:.3g}, p95 {np.quantile(dn, 0.95) if dn.size else 0:.3g}")
-        assert redecided <= 0.08 * gid.size, f"{name}: the audit sent {redecided} of {gid.size} pixels to f64"
+        # (an instance is not audited: every ray whose reference-order walk reaches it is re-decided in f64)
+        bound = 0.5 if name == "final_scene_instanced" else 0.08
+        assert redecided <= bound * gid.size, f"{name}: the audit sent {redecided} of {gid.size} pixels to f64"
         if rel_t.size:
             assert rel_t.max() <= 1e-5
             assert np.quantile(dn, 0.95) <= 1e-5
@@ -78,7 +80,8 @@ def test_primary_hits_f32(name, w, earthmap):
 
 @pytest.mark.parametrize("name", ["random_scene", "two_spheres", "earth", "simple_light", "cube_scene",
                                   "small_scene", "cornell_box", "final_scene", "perlin_spheres", "final_scene_perlin",
-                                  "cornell_box_area", "area_light_plate", "random_scene_stdrng", "area_light_list"])
+                                  "cornell_box_area", "area_light_plate", "random_scene_stdrng", "area_light_list",
+                                  "final_scene_instanced"])
 def test_render_f64_follows_oracle_path_for_path(name, earthmap):
     """Both f64 walks against the oracle (main.rs:65-105 + hittable.rs:208-415), same seed: the reference-order BVH
     walk (RT_FLAG_FORCE_BVH: every work counter identical, nodes and primitive tests included) and the walk
@@ -128,7 +131,7 @@ def _chunk_means(render_chunk, spp, chunks, clip):
 
 @pytest.mark.parametrize("name,wavefront", [(n, False) for n in (
     "random_scene", "simple_light", "cornell_box", "earth", "small_scene", "final_scene", "bvh_stress", "perlin_spheres",
-    "cornell_box_area", "area_light_plate", "area_light_list")] + [
+    "cornell_box_area", "area_light_plate", "area_light_list", "final_scene_instanced")] + [
     # the wavefront-queue form (RT_FLAG_WAVEFRONT) against the ORACLE (main.rs:65-105), not only against
     # its sibling kernel (tests/test_gpu_wavefront.py)
     ("random_scene", True), ("final_scene", True), ("bvh_stress", True)])
@@ -143,7 +146,7 @@ def test_render_f32_within_monte_carlo_noise(name, wavefront, earthmap):
     spp, chunks = 512, 16
     # final_scene / bvh_stress: the reference's estimator has fireflies of 1e20 and more (fog gains energy per
     # scatter; glass next to the sky): compare chunk means clipped to the displayable range
-    clip = 4.0 if name in ("final_scene", "bvh_stress") else 0.0
+    clip = 4.0 if name in ("final_scene", "bvh_stress", "final_scene_instanced") else 0.0
     launches = []
 
     def gpu_chunk(off, n):
@@ -199,7 +202,7 @@ def test_leaf_list_path_refused_when_boxes_clip(earthmap):
     assert sa["nodes_visited"] > 0
 
 
-@pytest.mark.parametrize("name", ["random_scene", "final_scene", "bvh_stress", "earth"])
+@pytest.mark.parametrize("name", ["random_scene", "final_scene", "bvh_stress", "earth", "final_scene_instanced"])
 def test_ordered_walk_equals_reference_walk(name, earthmap):
     """Scenes too large for the leaf list take the near-child-first walk in f32 (verified-conservative
     boxes only); RT_FLAG_FORCE_BVH takes the reference's left-first walk (hittable.rs:400-412).  Both run
@@ -344,3 +347,27 @@ def test_production_walk_primary_hits_at_one_million_spheres():
     hit = b[0] != 0xFFFFFFFF
     assert hit.mean() > 0.5
     assert np.array_equal(a[1][hit], b[1][hit]) and np.array_equal(a[2][hit], b[2][hit])
+
+
+def test_an_instance_renders_what_its_flattened_scene_renders(earthmap):
+    """Scene 16 holds final_scene's 1000 small spheres as ONE Translate(Rotate(Bvh)) instance (hittable.rs:81-91 over a
+    sub-tree), scene 8 wraps each sphere by itself: the same primitives in the same places.  hit() returns the smallest
+    candidate t whatever the tree, draws are keyed, so both scenes trace the same paths: in f64 (the
+    instance arm of the reference-order walk against 1000 wrapper chains) and in f32 (both de-instanced)."""
+    import raytracer_amd as R
+    h = W
+    inst = R.DeviceScene(R.HostScene("final_scene_instanced", 1.0), 0)
+    flat = R.DeviceScene(R.HostScene("final_scene", 1.0), 0)
+    for kw, tol in (({"f64": True}, 1e-9), ({"f64": True, "force_bvh": True}, 1e-9), ({}, 1e-4), ({"force_bvh": True}, 1e-4)):
+        a, sa = inst.render(W, h, 16, 50, seed=5, stats=True, **kw)
+        b, sb = flat.render(W, h, 16, 50, seed=5, stats=True, **kw)
+        for k in ("rays", "closest_hits", "diffuse_vertices", "specular_vertices", "emitter_hits", "misses"):
+            assert abs(sa[k] - sb[k]) <= 2e-3 * sb[k] + 2, (kw, k, sa[k], sb[k])
+        fin = np.isfinite(a).all(axis=-1) & np.isfinite(b).all(axis=-1)
+        same = np.isclose(a[fin], b[fin], rtol=tol, atol=tol).all(axis=-1)
+        assert same.mean() >= 0.995, (kw, same.mean())
+    # the instance arm really ran: the reference-order walk counts one Rotate / Translate visit per ENTRY of the
+    # instance, the flattened scene one per wrapped sphere it tests
+    _, si = inst.render(W, h, 4, 50, seed=5, stats=True, f64=True, force_bvh=True)
+    _, sf = flat.render(W, h, 4, 50, seed=5, stats=True, f64=True, force_bvh=True)
+    assert 0 < si["rotate_visits"] < sf["rotate_visits"] / 4
