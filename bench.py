@@ -279,7 +279,7 @@ OTHER_CONFIGS = [
     ("C4", "bvh_stress", 3840, 16.0 / 9.0, 1000000, 256, 4, 50, (640, 1)),
     # beyond BASELINE.json: the C4 scene grown until its tree (8 M leaves x 64-B nodes = 512 MB + 128 MB of spheres)
     # no longer fits the 256 MiB Infinity Cache — the configuration in which the walk really streams from HBM
-    ("C4-hbm", "bvh_stress", 1920, 16.0 / 9.0, 8000000, 256, 2, 50, None),
+    ("C4-hbm", "bvh_stress", 1920, 16.0 / 9.0, 8000000, 256, 8, 50, None),
 ]
 
 

@@ -16,7 +16,7 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 L = [f"# rocprofv3 summary `{tag}` (final build of the round)", "",
      "Command of the kernel trace: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline`",
-     f"(the default bench: Cornell 1024^2 x 4096 spp f32, its f64 leg, and the C1 / C3 / C4 lines), `tools/profile_round.sh {tag}`;",
+     f"(the default bench: Cornell 1024^2 x 4096 spp on the f64 kernel = the headline, its f32 peer leg, and the C1 / C3 / C4 / C4-hbm lines with their f64 samples), `tools/profile_round.sh {tag}`;",
      f"this file is written by `tools/summarize_round.py {tag}`.", ""]
 
 
@@ -59,10 +59,10 @@ if traffic:
 
 walks = [("c1", "C1 random_scene 400x225 x 100 spp"), ("c3", "C3 final_scene 1024^2 x 512 spp"),
          ("c4", "C4 bvh_stress 10^6 spheres 3840x2160 x 4 spp"),
-         ("f64", "f64 audit kernel, Cornell 1024^2 x 256 spp")]
+         ("f64", "f64 kernel (the headline's), Cornell 1024^2 x 1024 spp")]
 have = [(k, t) for k, t in walks if os.path.exists(os.path.join(src, f"walk_{k}.txt"))]
 if have:
-    L += ["## SQ / TCC / TCP passes of the BVH-bound configs and of the f64 audit kernel (`tools/pmc_walk.sh`, one render each, five `--pmc` runs)", ""]
+    L += ["## SQ / TCC / TCP passes of the BVH-bound configs and of the f64 kernel (`tools/pmc_walk.sh`, one render each, five `--pmc` runs)", ""]
     for k, title in have:
         body = []
         for line in open(os.path.join(src, f"walk_{k}.txt")):
@@ -71,7 +71,7 @@ if have:
                 body.append(line)
             elif "kernel_ms" in line and not any("kernel_ms" in b for b in body):
                 body.append(line.split(":", 1)[-1])
-        kern = "render_persist_kernel<double, ..., TRAV_REFERENCE>" if k == "f64" else "render_units_kernel"
+        kern = "render_persist_kernel<double, ..., TRAV_LEAVES>" if k == "f64" else "render_units_kernel"
         L += [f"### {title} — `{kern}`", "", "```"] + body + ["```", ""]
 
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
