@@ -160,7 +160,7 @@ class Workload:
         d = self.hs.desc
         small = "RT_FLAG_FORCE_BVH" in counted_on or d.n_nodes == 0
         if f64:
-            return "render_persist_kernel<double, ..., TRAV_LEAVES>" if small else "render_persist_kernel<double, ..., TRAV_REFERENCE>"
+            return "render_persist_kernel<double, ..., TRAV_LEAVES>" if small else "render_persist_kernel<double, ..., TRAV_ORDERED>"
         return "render_persist_kernel<float, ..., TRAV_LINEAR>" if small else "render_units_kernel"
 
 
@@ -275,8 +275,8 @@ def peer_leg(wl, args, f64):
 OTHER_CONFIGS = [
     # (tag, scene, width, aspect, n, full spp, bench spp, depth, f64 leg: (width, spp) or None)
     ("C1", "random_scene", 400, 16.0 / 9.0, 0, 100, 100, 50, (400, 100)),
-    ("C3", "final_scene", 1024, 1.0, 0, 10000, 512, 50, (1024, 16)),
-    ("C4", "bvh_stress", 3840, 16.0 / 9.0, 1000000, 256, 4, 50, (640, 1)),
+    ("C3", "final_scene", 1024, 1.0, 0, 10000, 512, 50, (1024, 64)),
+    ("C4", "bvh_stress", 3840, 16.0 / 9.0, 1000000, 256, 4, 50, (1920, 2)),
     # beyond BASELINE.json: the C4 scene grown until its tree (8 M leaves x 64-B nodes = 512 MB + 128 MB of spheres)
     # no longer fits the 256 MiB Infinity Cache — the configuration in which the walk really streams from HBM
     ("C4-hbm", "bvh_stress", 1920, 16.0 / 9.0, 8000000, 256, 8, 50, None),
@@ -286,7 +286,7 @@ OTHER_CONFIGS = [
 def other_configs(R, torch, device, skip_big=False):
     """BASELINE.json configs C1, C3, C4 on one GPU at bounded spp (the rates are spp-independent once a launch is
     long enough; C1 is run at its full size), f32 product walk; `f64` = the same scene on the f64 kernel
-    (reference-order walk: the kernel that follows the oracle path for path) on a bounded sample."""
+    (the ordered walk in f64: same paths as the oracle's reference-order walk, fewer node visits) on a bounded sample."""
     lines = []
     for tag, scene, width, aspect, n, full_spp, spp, depth, leg64 in OTHER_CONFIGS:
         if skip_big and n > 1000000:
@@ -313,7 +313,7 @@ def other_configs(R, torch, device, skip_big=False):
             s64 = float(w64) * wl.height * spp64
             line["f64"] = {"workload": workload_key(scene, w64, wl.height, spp64, depth, n, True), "ms_per_step": 1e3 * secs,
                            "value": rays / secs / 1e6, "unit": "Mrays/s", "msamples_per_s": s64 / secs / 1e6,
-                           "rays_per_sample": rays / s64, "kernel": "render_persist_kernel<double, ..., TRAV_REFERENCE>"}
+                           "rays_per_sample": rays / s64, "kernel": "render_persist_kernel<double, ..., TRAV_ORDERED>"}
             del wl
             torch.cuda.empty_cache()
         lines.append(line)

@@ -627,6 +627,88 @@ struct OrderedWalk {
   }
 };
 
+// The ordered walk in any precision, run to completion (what the f64 kernel walks on scenes too large for the leaf
+// list): the same tree — Node2's f32 boxes are rounded OUTWARD from the f64 bounds, so testing them in R arithmetic
+// (a float converts to a double exactly) only culls what no leaf below can be hit in; the leaves are tested by the
+// literal R-precision code (prim_t / complex_t, an instance's leaves as their synthesized complexes).  By the argument
+// above the winner, its t and the keyed draws are those of the reference-order walk bit for bit; only the work
+// counters (nodes visited, leaves tested) differ.  Phased like traverse(): node steps together, leaf tests together.
+RT_DEV double next_up(double x) {
+  return x < Consts<double>::inf ? __longlong_as_double(__double_as_longlong(x) + 1ll) : x;
+}
+template <typename R> RT_DEV uint16_t entry_bits_below(R t) {  // a positive distance in 16 bits, never above t
+  float f = (float)t;
+  if constexpr (sizeof(R) == 8) {
+    if ((double)f > t) f = __uint_as_float(__float_as_uint(f) - 1u);  // (the conversion rounded up)
+  }
+  return OrderedWalk::entry_bits(f);
+}
+template <typename R, bool STATS>
+RT_DEV void traverse_ordered(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, uint32_t* stack, uint16_t* stack_t,
+                             uint32_t stride, R& closest, uint32_t& best, Cnt<STATS>& cnt) {
+  closest = Consts<R>::inf;
+  best = REF_NONE;
+  uint32_t cur = sc.root2;
+  if (cur == REF_NONE) return;
+  const Vec3<R> inv_d = inverse3(r.d);
+  const R a = sqrlen(r.d);
+  uint32_t sp = 0;
+  bool walking = true;
+  auto pop = [&]() -> bool {  // next entry whose box is not entered beyond the closest hit
+    for (;;) {
+      if (sp == 0) return false;
+      --sp;
+      cur = stack[sp * stride];
+      if (!((R)OrderedWalk::entry_float(stack_t[sp * stride]) > closest)) return true;
+    }
+  };
+  for (;;) {
+    while (walking && !(cur & REF_LEAF)) {
+      cnt.template inc<ST_NODES>(2);
+      const Node2 n = sc.nodes2[cur];
+      const R t_incl = next_up(closest);
+      R lb[6], rb[6];
+      for (int c = 0; c < 6; ++c) {
+        lb[c] = (R)n.lbox[c];
+        rb[c] = (R)n.rbox[c];
+      }
+      R l0 = t_min, l1 = t_incl, r0 = t_min, r1 = t_incl;
+      const bool hl = slab_hit(lb, lb + 3, r.o, inv_d, l0, l1);
+      const bool hr = slab_hit(rb, rb + 3, r.o, inv_d, r0, r1);
+      const bool left_first = hl && (!hr || l0 <= r0);
+      if (hl && hr) {
+        stack[sp * stride] = left_first ? n.right : n.left;
+        stack_t[sp * stride] = entry_bits_below(left_first ? r0 : l0);
+        ++sp;
+      }
+      cur = left_first ? n.left : n.right;
+      if (!(hl || hr)) walking = pop();
+    }
+    if (!walking) break;
+    {
+      const R t_incl = next_up(closest);
+      R t;
+      bool h;
+      if constexpr (sizeof(R) == 4)
+        h = leaf_t_unified(sc, cur, r, inv_d, a, t_min, t_incl, rng, t, cnt);
+      else if (ref_kind(cur) == LEAF_COMPLEX)
+        h = complex_t(sc, ref_index(cur), r, t_min, t_incl, rng, t, cnt);
+      else
+        h = prim_t(sc, cur, r, inv_d, a, t_min, t_incl, t, cnt);
+      if (h) {
+        bool take = t < closest;
+        if (t == closest && best != REF_NONE) take = leaf_rank(sc, cur) < leaf_rank(sc, best);
+        if (take) {
+          closest = t;
+          best = cur;
+        }
+      }
+    }
+    walking = pop();
+    if (!walking) break;
+  }
+}
+
 // Small scenes (a handful of leaves): test every leaf in BVH left-first DFS order with the
 // same shrinking t_max and the same strict `<` — exactly the reference's List arm
 // (hittable.rs:387-399).  A leaf that the BVH would have pruned can only be hit outside

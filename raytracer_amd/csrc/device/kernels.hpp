@@ -1227,6 +1227,8 @@ constexpr uint32_t UNIT_RING = 32;
 // TRAV_REFERENCE (any precision): the same hand-out around the reference-order BVH walk — what scenes with
 // non-conservative boxes, RT_FLAG_FORCE_BVH and the f64 audit run on; EARLY_EXIT / NOISE as in render_kernel.
 // TRAV_LEAVES (f64): around traverse_leaves, the hot scene arrays staged in LDS once per workgroup.
+// TRAV_ORDERED (f64): around traverse_ordered — the SAH tree walked nearer child first in the caller's precision, for
+// scenes too large for the leaf list (same images as the reference-order walk, a fraction of its node visits).
 #ifndef RT_LEAVES_MIN_WAVES
 #define RT_LEAVES_MIN_WAVES 4
 #endif
@@ -1234,9 +1236,12 @@ template <typename R, bool STATS, int TRAV = TRAV_LINEAR, bool EARLY_EXIT = true
 __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WAVES : TRAV == TRAV_LEAVES ? RT_LEAVES_MIN_WAVES : (sizeof(R) == 8 ? RT_RENDER_F64_MIN_WAVES : RT_RENDER_MIN_WAVES))
     render_persist_kernel(SceneView<R> sc_in, CameraView<R> cam, RenderArgs a, R* __restrict__ accum, DeviceStats* stats) {
   constexpr bool LINEAR = TRAV == TRAV_LINEAR, LEAVES = TRAV == TRAV_LEAVES;
-  static_assert(TRAV == TRAV_LINEAR || TRAV == TRAV_REFERENCE || TRAV == TRAV_LEAVES, "leaf list or reference-order walk");
-  extern __shared__ uint32_t lds_stack[];  // TRAV_REFERENCE: the walk's stack
+  static_assert(TRAV == TRAV_LINEAR || TRAV == TRAV_REFERENCE || TRAV == TRAV_LEAVES || TRAV == TRAV_ORDERED,
+                "leaf list, reference-order or (run to completion) ordered walk");
+  extern __shared__ uint32_t lds_stack[];  // TRAV_REFERENCE / TRAV_ORDERED: the walk's stack
   [[maybe_unused]] uint32_t* stack = lds_stack + threadIdx.x;
+  // TRAV_ORDERED: 16-bit box-entry distances behind the 32-bit references (launch_impl.hpp sizes both)
+  [[maybe_unused]] uint16_t* stack_t = reinterpret_cast<uint16_t*>(lds_stack + (size_t)a.stack_depth * BLOCK) + threadIdx.x;
   __shared__ Light<R> s_lights[LDS_MAX_LIGHTS];
   __shared__ float s_lin[LINEAR ? LIN_MAX_LEAVES * LIN_DWORDS : 1];
   // TRAV_LEAVES: the arrays a leaf test reads (hittable.rs:42-91 flattened), staged so that the wave-uniform leaf loop
@@ -1408,6 +1413,8 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
         traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
     } else if constexpr (LEAVES) {
       traverse_leaves(sc, ray, R(0.001), rng, t, best, cnt);
+    } else if constexpr (TRAV == TRAV_ORDERED) {
+      traverse_ordered(sc, ray, R(0.001), rng, stack, stack_t, (uint32_t)BLOCK, t, best, cnt);
     } else {
       traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
     }

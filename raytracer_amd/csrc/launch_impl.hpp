@@ -115,6 +115,16 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
                   dstats);
       return hipGetLastError();
     }
+    if (shape.trav == TRAV_ORDERED && shape.unit_samples > 0 && !sc.has_noise) {  // big scenes: the ordered walk in f64
+      const size_t lds2 = lds + lds / 2;  // 32-bit refs + 16-bit entry distances
+      if (stats)
+        RT_LAUNCH((render_persist_kernel<RT_REAL, true, TRAV_ORDERED, RT_EARLY_EXIT, false>), grid, block, lds2, st, sc, cam, a,
+                  accum, dstats);
+      else
+        RT_LAUNCH((render_persist_kernel<RT_REAL, false, TRAV_ORDERED, RT_EARLY_EXIT, false>), grid, block, lds2, st, sc, cam, a,
+                  accum, dstats);
+      return hipGetLastError();
+    }
     if (shape.trav == TRAV_REFERENCE && shape.unit_samples > 0) {  // persistent form of the audit kernel (rt_api.hip: make_shape)
       if (stats)
         RT_LAUNCH((render_persist_kernel<RT_REAL, true, TRAV_REFERENCE, RT_EARLY_EXIT, true>), grid, block, lds, st, sc, cam, a,

@@ -120,12 +120,13 @@ struct TreeFacts {
 template <typename R> struct SceneSide {
   DeviceBuffers bufs;
   SceneView<R> view{};
-  uint32_t ordered_root = RT_REF_NONE, ordered_height = 0;  // the ordered walk's tree (f32 side), if built
+  uint32_t ordered_root = RT_REF_NONE, ordered_height = 0;  // the ordered walk's tree, if built
 };
 
 template <typename R>
 hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& complexes, const std::vector<uint32_t>& linear,
-                      const TreeFacts& facts, SceneSide<R>& s) {
+                      const TreeFacts& facts, SceneSide<R>& s, std::vector<Node2>& tree2, uint32_t& tree2_root,
+                      uint32_t& tree2_height) {
   // BAKED spheres.  A Translate / Rotate chain (no medium) around a static Sphere whose material never reads uv is,
   // for every quantity the path uses, a Sphere at the mapped centre: t is frame-independent, the world normal
   // (p - c') / r is the rotated local normal, front_face follows.  Such complex leaves get a plain sphere record
@@ -190,7 +191,29 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
   // reference's tree above stays what the reference-order walk and parity level 1 use.  Each Node2
   // holds both children's boxes beside their references.  RT_ORDERED_REFERENCE_TREE=1 (A/B) mirrors
   // the reference's tree into Node2 form instead.
+  // The f64 side walks the SAME tree (traverse_ordered: the f32 boxes are outward-rounded, so they cull conservatively in
+  // f64 as well), with the baked sphere records turned back into the complexes they stand for: its leaf tests are the
+  // literal ones.  The f32 side is built first and leaves the tree in `tree2`.
   std::vector<Node2> nodes2;
+  if constexpr (sizeof(R) == 8) {
+    if (tree2_root != RT_REF_NONE) {
+      std::vector<uint32_t> unbake(baked_sphere.size(), RT_REF_NONE);
+      for (uint32_t i = 0; i < n_complex; ++i)
+        if (baked[i] != RT_REF_NONE) unbake[baked[i] - d.n_spheres] = i;
+      auto f64_ref = [&](uint32_t ref) -> uint32_t {
+        if (ref != RT_REF_NONE && (ref & RT_REF_LEAF) && RT_REF_KIND(ref) == RT_LEAF_SPHERE && RT_REF_INDEX(ref) >= d.n_spheres)
+          return RT_MAKE_LEAF(RT_LEAF_COMPLEX, unbake[RT_REF_INDEX(ref) - d.n_spheres]);
+        return ref;
+      };
+      nodes2 = std::move(tree2);
+      for (Node2& n : nodes2) {
+        n.left = f64_ref(n.left);
+        n.right = f64_ref(n.right);
+      }
+      s.ordered_root = tree2_root;
+      s.ordered_height = tree2_height;
+    }
+  }
   if constexpr (sizeof(R) == 4) {
     bool has_inst = false;
     for (const Complex& c : complexes) has_inst |= (c.flags & CXF_INSTANCE) != 0;
@@ -227,6 +250,9 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
       s.ordered_root = d.root;
       s.ordered_height = accel::height_of(nodes2, d.root);
     }
+    tree2 = nodes2;
+    tree2_root = s.ordered_root;
+    tree2_height = s.ordered_height;
   }
   std::vector<Real4<R>> spheres(d.n_spheres);
   std::vector<Attr> sphere_attr(d.n_spheres);
@@ -965,8 +991,10 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
   s->boxes_conservative = facts.conservative;
   s->safe_t_lo = facts.t_lo;
   s->safe_t_hi = facts.t_hi;
-  if ((e = build_side<float>(*d, complexes, linear, facts, s->f32)) != hipSuccess ||
-      (e = build_side<double>(*d, complexes, linear, facts, s->f64)) != hipSuccess ||
+  std::vector<Node2> tree2;  // the ordered walk's tree: built by the f32 side, shared with the f64 side
+  uint32_t tree2_root = RT_REF_NONE, tree2_height = 0;
+  if ((e = build_side<float>(*d, complexes, linear, facts, s->f32, tree2, tree2_root, tree2_height)) != hipSuccess ||
+      (e = build_side<double>(*d, complexes, linear, facts, s->f64, tree2, tree2_root, tree2_height)) != hipSuccess ||
       (e = hipMalloc((void**)&s->dstats, (size_t)rt_scene::RING_CHUNKS * rt_scene::RING_CHUNK_SLOTS * NOALLOC_SLOT_BYTES)) != hipSuccess ||
       (e = hipEventCreate(&s->ev0)) != hipSuccess || (e = hipEventCreate(&s->ev1)) != hipSuccess) {
     delete s;
@@ -1006,9 +1034,14 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   static const bool f64_no_leaves = getenv("RT_F64_NO_LEAVES") != nullptr;
   if (f64 && fast_ok && !f64_no_leaves && !s->f64.view.has_noise && s->f64.view.n_leaf_list > 0 && max_depth > 0 && n_samples > 0)
     sh.trav = 3;
+  // f64, larger scenes: the ordered walk in f64 (traverse_ordered, persistent form only); RT_F64_NO_ORDERED=1 (A/B)
+  static const bool f64_no_ordered = getenv("RT_F64_NO_ORDERED") != nullptr;
+  const bool ordered64 = f64 && sh.trav == 0 && fast_ok && !f64_no_ordered && !s->f64.view.has_noise &&
+                         s->f64.ordered_root != RT_REF_NONE && max_depth > 0 && n_samples > 0;
+  if (ordered64) sh.trav = 2;
   uint32_t tx = (w + 15) / 16, ty = (h + 15) / 16;
   sh.tiles = tx * ty;
-  sh.stack_depth = sh.trav == 2 ? std::max(s->f32.ordered_height, 1u) : s->stack_depth;
+  sh.stack_depth = sh.trav == 2 ? std::max(f64 ? s->f64.ordered_height : s->f32.ordered_height, 1u) : s->stack_depth;
   // ordered walk: the longer a scene's walks, the smaller the idle fraction worth interrupting them for
   // (measured optimum, re-tuned on the final kernels: 6/8 at ~500-1500 nodes, 4/8 at 20 k, 3/8 at 1 M)
   static const char* re = getenv("RT_REFILL_EIGHTHS");  // tuning override
@@ -1078,7 +1111,7 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   // workgroup per (tile, split) (A/B).  Not for the f32 reference-order kernel: its jobs are short-path scenes
   // (the reference's default job, depth 5: 35.9 ms as a grid, 38.2 ms at best in this form).
   static const bool ref_grid = getenv("RT_REF_GRID") != nullptr;
-  if ((sh.trav == 0 || sh.trav == 3) && f64 && (!ref_grid || sh.trav == 3) && max_depth > 0 && n_samples > 0) {
+  if ((sh.trav == 0 || sh.trav == 3 || ordered64) && f64 && (!ref_grid || sh.trav != 0) && max_depth > 0 && n_samples > 0) {
     // (leaf-list form at the metric's 4096 spp, units of 16 / 32 / 64 / 128 / 256 samples: 1511 / 1518 / 1545 / 1603 / 1751 ms)
     const uint32_t auto_unit = sh.trav == 3 ? std::min(16u, std::max(2u, n_samples / 32)) : std::min(8u, std::max(2u, n_samples / 16));
     sh.unit_samples = std::max(1u, std::min(us ? (uint32_t)std::max(1, atoi(us)) : auto_unit, n_samples));
@@ -1091,13 +1124,14 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
       sh.splits = 1;
     } else {
       sh.unit_samples = 0;
-      sh.trav = 0;  // (the leaf-list form exists as a persistent kernel only)
+      sh.trav = 0;  // (the leaf-list and ordered f64 forms exist as persistent kernels only)
+      sh.stack_depth = s->stack_depth;
     }
   }
   // Ordered-walk scenes: the same, with the refill kernel's job sharing (render_units_kernel).  RT_REFILL_GRID keeps
   // the one-workgroup-per-(tile, split) form (A/B).
   static const bool refill_grid = getenv("RT_REFILL_GRID") != nullptr || getenv("RT_ORDERED_NO_REFILL") != nullptr;
-  if (sh.trav == 2 && !refill_grid && max_depth > 0 && n_samples > 0) {
+  if (sh.trav == 2 && !f64 && !refill_grid && max_depth > 0 && n_samples > 0) {
     // unit size: 8 samples of a tile amortise a unit's hand-over and flush (final_scene 1024^2 x 512 spp: 2 -> 12.3,
     // 4 -> 12.7, 8 -> 12.8, 32 -> 12.2 Grays/s), but a short launch needs >= 16 units per wave slot of the chip to end
     // evenly (random_scene 400 x 225 x 100 spp: 2 -> 8.8, 4 -> 8.3, 8 -> 7.6 Grays/s)

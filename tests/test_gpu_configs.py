@@ -44,15 +44,22 @@ def test_c1_full_config_against_the_oracle():
     assert h == 225
     ds = R.DeviceScene(R.HostScene(0, ASPECT), 0)
     o, ocnt, _ = O.OracleScene(0, ASPECT).render(w, h, spp, depth, seed=1)
-    g, gst = ds.render(w, h, spp, depth, seed=1, stats=True, f64=True)
-    assert (np.isfinite(o) == np.isfinite(g)).all()
-    fin = np.isfinite(o)
-    err = np.abs(g - o)[fin] / (1.0 + np.abs(o[fin]))
-    # 9 M paths: now and then a last-ulp libm difference flips a branch and that one sample parts ways
-    assert np.quantile(err, 0.99) <= 1e-9, np.quantile(err, 0.99)
-    assert (err > 1e-9).mean() <= 5e-3, (err > 1e-9).mean()
-    for k in ("rays", "nodes_visited", "sphere_tests", "closest_hits", "diffuse_vertices", "specular_vertices", "misses"):
-        assert abs(gst[k] - ocnt[k]) <= 1e-4 * max(1, ocnt[k]), (k, gst[k], ocnt[k])
+    # both f64 walks: the reference-order walk of the reference's tree (RT_FLAG_FORCE_BVH: every work counter is the
+    # oracle's) and the default, the ordered walk of the SAH tree (same paths, fewer node visits and leaf tests)
+    for force_bvh in (True, False):
+        g, gst = ds.render(w, h, spp, depth, seed=1, stats=True, f64=True, force_bvh=force_bvh)
+        assert (np.isfinite(o) == np.isfinite(g)).all()
+        fin = np.isfinite(o)
+        err = np.abs(g - o)[fin] / (1.0 + np.abs(o[fin]))
+        # 9 M paths: now and then a last-ulp libm difference flips a branch and that one sample parts ways
+        assert np.quantile(err, 0.99) <= 1e-9, np.quantile(err, 0.99)
+        assert (err > 1e-9).mean() <= 5e-3, (err > 1e-9).mean()
+        work = ("nodes_visited", "sphere_tests") if force_bvh else ()
+        for k in ("rays", "closest_hits", "diffuse_vertices", "specular_vertices", "misses") + work:
+            assert abs(gst[k] - ocnt[k]) <= 1e-4 * max(1, ocnt[k]), (k, gst[k], ocnt[k])
+        if not force_bvh:
+            assert gst["nodes_visited"] < 0.6 * ocnt["nodes_visited"]
+    g, gst = ds.render(w, h, spp, depth, seed=1, stats=True, f64=True, force_bvh=True)
     # the product kernel, same seed: same Philox words, the same paths except where a branch hangs on f32 rounding
     f, fst = ds.render(w, h, spp, depth, seed=1, stats=True)
     assert fst["nodes_visited"] < gst["nodes_visited"] / 2  # (own tree, near child first)
@@ -112,18 +119,22 @@ def test_c4_f64_audit_follows_the_oracle_at_one_million_spheres(million):
     assert np.array_equal(fid, oid)
     np.testing.assert_allclose(ft[hit], ot[hit], rtol=1e-5, atol=0)
     # level 3, path for path: same Philox words, same branches, same work counters
-    g, gst = ds.render(w, h, 2, 50, seed=11, sample_offset=5, stats=True, f64=True)
     o, ocnt, _ = orc.render(w, h, 2, 50, seed=11, sample_offset=5)
-    fin = np.isfinite(o) & np.isfinite(g)
-    assert (np.isfinite(o) == np.isfinite(g)).all()
-    err = np.abs(g - o)[fin] / (1.0 + np.abs(o[fin]))
-    # 40 rays per sample in this scene (glass and metal between the spheres): now and then a last-ulp difference of
-    # libm (sin, cos) flips a branch somewhere down such a path and that sample parts ways — a handful of the 6912
-    # pixel channels; everything else is equal to rounding, and the work counters agree to the same few paths
-    assert (err > 1e-9).mean() <= 0.01, (err > 1e-9).mean()
-    assert np.median(err) <= 1e-13
-    for k in ("rays", "nodes_visited", "sphere_tests", "closest_hits", "diffuse_vertices", "specular_vertices", "misses"):
-        assert abs(gst[k] - ocnt[k]) <= 1e-2 * ocnt[k] + 60, (k, gst[k], ocnt[k])
+    for force_bvh in (True, False):  # the reference-order walk (all work counters), then the default ordered f64 walk
+        g, gst = ds.render(w, h, 2, 50, seed=11, sample_offset=5, stats=True, f64=True, force_bvh=force_bvh)
+        fin = np.isfinite(o) & np.isfinite(g)
+        assert (np.isfinite(o) == np.isfinite(g)).all()
+        err = np.abs(g - o)[fin] / (1.0 + np.abs(o[fin]))
+        # 40 rays per sample in this scene (glass and metal between the spheres): now and then a last-ulp difference of
+        # libm (sin, cos) flips a branch somewhere down such a path and that sample parts ways — a handful of the 6912
+        # pixel channels; everything else is equal to rounding, and the work counters agree to the same few paths
+        assert (err > 1e-9).mean() <= 0.01, (err > 1e-9).mean()
+        assert np.median(err) <= 1e-13
+        work = ("nodes_visited", "sphere_tests") if force_bvh else ()
+        for k in ("rays", "closest_hits", "diffuse_vertices", "specular_vertices", "misses") + work:
+            assert abs(gst[k] - ocnt[k]) <= 1e-2 * ocnt[k] + 60, (k, gst[k], ocnt[k])
+        if not force_bvh:
+            assert gst["nodes_visited"] < ocnt["nodes_visited"] / 3
 
 
 def test_c4_refill_kernel_renders_the_reference_walks_paths_at_one_million_spheres(million):
