@@ -278,8 +278,12 @@ OTHER_CONFIGS = [
     ("C3", "final_scene", 1024, 1.0, 0, 10000, 512, 50, (1024, 64)),
     ("C4", "bvh_stress", 3840, 16.0 / 9.0, 1000000, 256, 4, 50, (1920, 2)),
     # beyond BASELINE.json: the C4 scene grown until its tree (8 M leaves x 64-B nodes = 512 MB + 128 MB of spheres)
-    # no longer fits the 256 MiB Infinity Cache — the configuration in which the walk really streams from HBM
-    ("C4-hbm", "bvh_stress", 1920, 16.0 / 9.0, 8000000, 256, 8, 50, None),
+    # no longer fits the 256 MiB Infinity Cache.  Dense (scene 7: the spheres fill a quarter of the volume) a path
+    # stays within a few units of the camera's visible shell and the touched set still caches (measured: 0.2 GB fetched
+    # per launch, profiles/r03_c4hbm_traffic.json); sparse (scene 17: every radius x 0.1) a ray crosses the whole volume
+    # and the walk streams the tree (3.3 TB/s fabric-side, L2 hit 0.49, profiles/r03_c4sparse_traffic.json) — the
+    # configuration that is priced against HBM
+    ("C4-hbm", "bvh_stress_sparse", 1920, 16.0 / 9.0, 8000000, 256, 8, 50, None),
 ]
 
 

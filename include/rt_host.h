@@ -20,7 +20,8 @@ typedef struct rth_scene rth_scene; /* a flattened scene + its camera, host memo
 
 typedef struct rth_scene_opts {
   int32_t scene_id;        /* main.rs:117-124: 0 random, 1 two_spheres, 2 earth, 3 simple_light, 4 cube_scene,
-                              other small_scene; plus 6 cornell_box, 7 bvh_stress, 8 final_scene, 9 mixed_scene (parity-test
+                              other small_scene; plus 6 cornell_box, 7 bvh_stress (17 bvh_stress_sparse: the same spheres at a
+                              tenth of their radii), 8 final_scene, 16 final_scene_instanced, 9 mixed_scene (parity-test
                               generator), and the extensions 10 perlin_spheres, 11 final_scene with the Perlin sphere,
                               12 cornell_box_area (the ceiling light a box: RT_LIGHT_CUBE + RT_MAT_AREA_LIGHT), 13 area_light_plate, 15 area_light_list (the box light in a List of three lights);
                               14 random_scene with its geometry drawn from StdRng::seed_from_u64(scene_seed) like

@@ -298,7 +298,10 @@ inline void area_light_list(SceneDef& s) {
 }
 
 // C4: ground + n random static spheres, material mix as random_scene; scene stream 0.
-inline void bvh_stress(SceneDef& s, uint64_t seed, uint32_t n) {
+// radius_scale 1: scene 7.  Scene 17 (bvh_stress_sparse) is the same draw sequence with every radius x 0.1: at 8 M spheres
+// scene 7 fills a quarter of its volume (rays end within a few units: the working set is the visible shell), scene 17
+// 0.03 % of it (a ray crosses the whole volume: the working set is the scene).
+inline void bvh_stress(SceneDef& s, uint64_t seed, uint32_t n, double radius_scale = 1.0) {
   Texture checker = Texture::checker_color(V3(0.2, 0.3, 0.1), V3(0.9, 0.9, 0.9));
   s.world.push_back(Hittable::new_sphere(V3(0.0, -1000.0, 0.0), 1000.0, Material::lambertian_tex(checker)));
   Rng rng = scene_rng(seed, 0);
@@ -307,7 +310,7 @@ inline void bvh_stress(SceneDef& s, uint64_t seed, uint32_t n) {
     double cx = rng.range(-40.0, 40.0);
     double cy = rng.range(0.1, 20.0);
     double cz = rng.range(-40.0, 40.0);
-    double radius = rng.range(0.05, 0.15);
+    double radius = rng.range(0.05, 0.15) * radius_scale;
     Material m;
     if (choose_mat < 0.8) {
       V3 r1 = random_vector(rng);
@@ -529,6 +532,7 @@ inline SceneDef build_scene_def(const SceneSpec& spec) {
     case 14: random_scene_stdrng(s, spec.scene_seed); break;
     case 15: area_light_list(s); break;
     case 16: final_scene_instanced(s, spec); break;
+    case 17: bvh_stress(s, spec.scene_seed, spec.n, 0.1); break;
     default: small_scene(s); break;
   }
   return s;

@@ -14,7 +14,7 @@ SCENE_IDS = {
     "random_scene": 0, "two_spheres": 1, "earth": 2, "simple_light": 3, "cube_scene": 4, "small_scene": 5,
     "cornell_box": 6, "bvh_stress": 7, "final_scene": 8, "mixed_scene": 9, "perlin_spheres": 10, "final_scene_perlin": 11,
     "cornell_box_area": 12, "area_light_plate": 13, "random_scene_stdrng": 14, "area_light_list": 15,
-    "final_scene_instanced": 16,
+    "final_scene_instanced": 16, "bvh_stress_sparse": 17,
 }
 _NEEDS_EARTHMAP = (2, 4, 8, 11, 16)
 

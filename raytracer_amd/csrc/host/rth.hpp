@@ -169,7 +169,8 @@ SceneDef earth(const SceneOpts& o);              // scenes.rs:125-131
 SceneDef simple_light();                         // scenes.rs:133-175
 SceneDef cube_scene(const SceneOpts& o);         // scenes.rs:177-192
 SceneDef cornell_box();                          // BASELINE.json configs[1], [4]
-SceneDef bvh_stress(uint64_t seed, uint32_t n);  // BASELINE.json configs[3]
+SceneDef bvh_stress(uint64_t seed, uint32_t n, double radius_scale = 1.0);  // BASELINE.json configs[3]; scene 17
+                                                                            // (bvh_stress_sparse): every radius x 0.1
 SceneDef final_scene(const SceneOpts& o, bool perlin = false, bool instanced = false);  // BASELINE.json configs[2]; perlin: scene 11
                                                                  // (extension); instanced: scene 16, the 1000 spheres as ONE
                                                                  // Translate(Rotate(Bvh)) instance

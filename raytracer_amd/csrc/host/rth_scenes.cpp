@@ -181,7 +181,7 @@ SceneDef area_light_list() {  // 15: the box light of scene 13 in a List with a 
   return s;
 }
 
-SceneDef bvh_stress(uint64_t seed, uint32_t n) {
+SceneDef bvh_stress(uint64_t seed, uint32_t n, double radius_scale) {
   SceneDef s = with_reference_view();
   s.world.reserve((size_t)n + 1);
   s.world.push_back(Hittable::new_sphere(
@@ -193,7 +193,7 @@ SceneDef bvh_stress(uint64_t seed, uint32_t n) {
     const double x = r.range(-40.0, 40.0);
     const double y = r.range(0.1, 20.0);
     const double z = r.range(-40.0, 40.0);
-    const double radius = r.range(0.05, 0.15);
+    const double radius = r.range(0.05, 0.15) * radius_scale;
     Material m;
     if (choose_mat < 0.8) {
       Vector v1 = random_vector(r), v2 = random_vector(r);
@@ -385,6 +385,7 @@ SceneDef scene_by_id(const SceneOpts& o) {
     case 14: return random_scene_stdrng(o.scene_seed);
     case 15: return area_light_list();
     case 16: return final_scene(o, false, true);
+    case 17: return bvh_stress(o.scene_seed, o.n, 0.1);
     default: return small_scene();  // main.rs:123
   }
 }

@@ -35,6 +35,8 @@ SCENES = {
     "area_light_list": (15, 1.0, 0, 8),  # the box light inside a lights List (with a sphere lamp and a non-emitting bead)
     # final_scene with its 1000 small spheres as ONE Translate(Rotate(Bvh)) instance (hittable.rs:81-91 over a Bvh)
     "final_scene_instanced": (16, 1.0, 0, 50),
+    # bvh_stress with every radius x 0.1: rays cross the whole volume (the bench's HBM-streaming configuration)
+    "bvh_stress_sparse": (17, 16.0 / 9.0, 20000, 50),
 }
 
 

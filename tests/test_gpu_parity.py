@@ -55,7 +55,7 @@ def test_primary_hits_f32(name, w, earthmap):
     The audit must stay a filter, not a detour: it may hand at most 8 % of the pixels to the f64 kernel.
     Normals: 1e-5 is met wherever f32 STORAGE allows it — a sphere of radius r whose centre c is stored in f32 has
     its normal (p - c) / r known to 2^-24 |c| / r at best (bvh_stress: r = 0.05 at |c| = 40 gives 5e-5) — so the
-    bound is 1e-5 on 95 % of the pixels and 3e-4 on all."""
+    bound is 1e-5 on 95 % of the pixels and 3e-4 on all (bvh_stress_sparse, radii ten times smaller: 3e-3)."""
     hs, ds, os_, _, _ = _pair(name, earthmap)
     h = max(2, int(w / SCENES[name][1]))
     for fast in (False, True):
@@ -75,7 +75,7 @@ def test_primary_hits_f32(name, w, earthmap):
         if rel_t.size:
             assert rel_t.max() <= 1e-5
             assert np.quantile(dn, 0.95) <= 1e-5
-            assert dn.max() <= 3e-4
+            assert dn.max() <= (3e-3 if name == "bvh_stress_sparse" else 3e-4)
 
 
 @pytest.mark.parametrize("name", ["random_scene", "two_spheres", "earth", "simple_light", "cube_scene",

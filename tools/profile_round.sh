@@ -14,7 +14,8 @@ bash tools/pmc_traffic.sh ${tag}_cornell "cornell_box 1024x1024, 4096 spp, max d
 bash tools/pmc_traffic.sh ${tag}_c1 "random_scene 400x225, 100 spp, max depth 50" --precision f32 --scene random_scene --width 400 --aspect $A --spp 100 &&
 bash tools/pmc_traffic.sh ${tag}_c3 "final_scene 1024x1024, 512 spp, max depth 50" --precision f32 --scene final_scene --width 1024 --aspect 1 --spp 512 &&
 bash tools/pmc_traffic.sh ${tag}_c4 "bvh_stress 3840x2160, 4 spp, max depth 50, n=1000000" --precision f32 --scene bvh_stress --width 3840 --aspect $A --spp 4 --n 1000000 &&
-bash tools/pmc_traffic.sh ${tag}_c4hbm "bvh_stress 1920x1080, 8 spp, max depth 50, n=8000000" --precision f32 --scene bvh_stress --width 1920 --aspect $A --spp 8 --n 8000000 || exit 1
+bash tools/pmc_traffic.sh ${tag}_c4hbm "bvh_stress 1920x1080, 8 spp, max depth 50, n=8000000" --precision f32 --scene bvh_stress --width 1920 --aspect $A --spp 8 --n 8000000 &&
+bash tools/pmc_traffic.sh ${tag}_c4sparse "bvh_stress_sparse 1920x1080, 8 spp, max depth 50, n=8000000" --precision f32 --scene bvh_stress_sparse --width 1920 --aspect $A --spp 8 --n 8000000 || exit 1
 [ -n "$SKIP_WALK" ] && exit 0
 bash tools/pmc_walk.sh ${tag}_c1 0 0 400 100 > $out/walk_c1.txt 2>&1 &&
 bash tools/pmc_walk.sh ${tag}_c3 8 0 1024 512 1.0 > $out/walk_c3.txt 2>&1 &&
