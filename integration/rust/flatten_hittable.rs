@@ -22,11 +22,38 @@ impl Hittable {
             Hittable::Empty => Ok((gpu::RT_REF_NONE, 0)), // only as the whole world (hittable.rs:171)
             Hittable::List(_) => Err("a List inside the world tree is not representable".into()),
             leaf => {
-                let object = fs.next_object;
-                fs.next_object += 1;
+                // inside an instance's sub-tree every leaf carries the id of the world object that owns the instance
+                let object = match fs.instance_owner {
+                    Some(owner) => owner,
+                    None => {
+                        fs.next_object += 1;
+                        fs.next_object - 1
+                    }
+                };
                 Ok((leaf.flatten_object(fs, object)?, 0))
             }
         }
+    }
+
+    /// The whole world: its tree first, then — behind it in the node arrays, so that the world's own nodes stay in
+    /// pre-order — the sub-tree of every instance (Translate / Rotate over a Bvh, hittable.rs:81-91 over 93-98; rt.h,
+    /// ABI version 3): the complex's `body` becomes the INDEX OF THE NODE that roots its sub-tree.  Returns
+    /// (root reference, height in nodes: the world's + 1 + the tallest sub-tree's, what rt_scene_create checks
+    /// against RT_MAX_BVH_HEIGHT).
+    pub fn flatten_world(&self, fs: &mut FlatScene) -> Result<(u32, u32), String> {
+        let (root, height) = self.flatten_into(fs)?;
+        let mut tallest = 0;
+        for (complex, owner, sub) in std::mem::take(&mut fs.pending_instances) {
+            fs.instance_owner = Some(owner);
+            let (sub_root, h) = unsafe { &*sub }.flatten_into(fs)?; // its leaves must be bare primitives
+            fs.instance_owner = None;
+            if sub_root & gpu::RT_REF_LEAF != 0 {
+                return Err("an instance of a single object: wrap the object itself".into());
+            }
+            fs.complex_body[complex as usize] = sub_root;
+            tallest = tallest.max(h);
+        }
+        Ok((root, if tallest > 0 { height + 1 + tallest } else { height }))
     }
 
     /// One world object: a primitive under a chain of Translate / Rotate / ConstantMedium wrappers,
@@ -86,7 +113,12 @@ impl Hittable {
                 fs.cube_object.push(object);
                 gpu::make_leaf(gpu::LEAF_CUBE, i)
             }
-            _ => return Err("a List, Bvh or Empty under a wrapper is not representable".into()),
+            Hittable::Bvh(_) if !ops.is_empty() && medium_material == gpu::RT_REF_NONE && fs.instance_owner.is_none() => {
+                // an INSTANCE: flatten_world() fills in the node index once the world's own tree is laid out
+                fs.pending_instances.push((fs.complex_body.len() as u32, object, cur as *const Hittable));
+                gpu::RT_REF_NONE
+            }
+            _ => return Err("a List or Empty under a wrapper, a medium over a Bvh, or nested instances: not representable".into()),
         };
         if ops.is_empty() {
             return Ok(body);

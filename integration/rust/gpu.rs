@@ -159,6 +159,12 @@ extern "C" {
     pub fn rt_primary_hits(scene: *mut RtScene, cam: *const RtCamera, width: u32, height: u32, seed: u64, time: f64,
                            prim_id: *mut u32, t: *mut f32, normal: *mut f32, uv: *mut f32, front_face: *mut u8) -> c_int;
     pub fn rt_tonemap(accum_rgb: *const f32, n_pixels: u64, spp: u64, rgb8: *mut u8);
+    // the same closure in the reference's own arithmetic (f64 throughout, alias.rs:4-7) and its tone map
+    pub fn rt_render_f64(scene: *mut RtScene, cam: *const RtCamera, p: *const RtParams, accum_rgb: *mut f64,
+                         stats: *mut RtStats) -> c_int;
+    pub fn rt_render_f64_device(scene: *mut RtScene, cam: *const RtCamera, p: *const RtParams, accum_rgb_device: *mut f64,
+                                accumulate: c_int, stream: *mut c_void, stats: *mut RtStats) -> c_int;
+    pub fn rt_tonemap_f64(accum_rgb: *const f64, n_pixels: u64, spp: u64, rgb8: *mut u8);
     pub fn rt_device_count() -> c_int;
     pub fn rt_last_error() -> *const c_char;
 }
@@ -203,6 +209,9 @@ pub struct FlatScene {
     pub light_sphere: Vec<f64>,
     pub background: [f64; 3],
     pub next_object: u32,
+    // instances (ABI version 3): see Hittable::flatten_world in flatten_hittable.rs
+    pub instance_owner: Option<u32>,
+    pub pending_instances: Vec<(u32, u32, *const Hittable)>, // (complex index, owner object, sub-tree)
 }
 
 impl FlatScene {
@@ -211,7 +220,7 @@ impl FlatScene {
     pub fn new(world: &Hittable, lights: &Option<Hittable>, background: Color) -> Result<Self, String> {
         let mut fs = FlatScene::default();
         fs.background = [background[0], background[1], background[2]];
-        let (root, height) = world.flatten_into(&mut fs)?; // flatten_hittable.rs
+        let (root, height) = world.flatten_world(&mut fs)?; // flatten_hittable.rs
         fs.root = root;
         fs.bvh_height = height;
         match lights {
