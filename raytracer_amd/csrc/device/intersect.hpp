@@ -643,70 +643,91 @@ template <typename R> RT_DEV uint16_t entry_bits_below(R t) {  // a positive dis
   }
   return OrderedWalk::entry_bits(f);
 }
-template <typename R, bool STATS>
-RT_DEV void traverse_ordered(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, uint32_t* stack, uint16_t* stack_t,
-                             uint32_t stride, R& closest, uint32_t& best, Cnt<STATS>& cnt) {
-  closest = Consts<R>::inf;
-  best = REF_NONE;
-  uint32_t cur = sc.root2;
-  if (cur == REF_NONE) return;
-  const Vec3<R> inv_d = inverse3(r.d);
-  const R a = sqrlen(r.d);
-  uint32_t sp = 0;
-  bool walking = true;
-  auto pop = [&]() -> bool {  // next entry whose box is not entered beyond the closest hit
+// ... as a resumable state machine (like OrderedWalk, in the caller's precision): the f64 kernel advances every lane of
+// a wave by node steps and leaf steps and lets the lanes whose walk is over go on to their vertex while the others keep
+// walking (state in registers, stack in LDS).
+template <typename R> struct OrderedWalkR {
+  uint32_t cur, sp, best;
+  R closest;
+  Vec3<R> inv_d;
+  R a;
+  RT_DEV bool start(const SceneView<R>& sc, const RayT<R>& r) {  // false: nothing to walk (empty world)
+    closest = Consts<R>::inf;
+    best = REF_NONE;
+    cur = sc.root2;
+    sp = 0;
+    inv_d = inverse3(r.d);
+    a = sqrlen(r.d);
+    return cur != REF_NONE;
+  }
+  RT_DEV bool pop(const uint32_t* stack, const uint16_t* stack_t, uint32_t stride) {  // next entry not entered beyond the closest hit
     for (;;) {
       if (sp == 0) return false;
       --sp;
       cur = stack[sp * stride];
       if (!((R)OrderedWalk::entry_float(stack_t[sp * stride]) > closest)) return true;
     }
-  };
-  for (;;) {
-    while (walking && !(cur & REF_LEAF)) {
-      cnt.template inc<ST_NODES>(2);
-      const Node2 n = sc.nodes2[cur];
-      const R t_incl = next_up(closest);
-      R lb[6], rb[6];
-      for (int c = 0; c < 6; ++c) {
-        lb[c] = (R)n.lbox[c];
-        rb[c] = (R)n.rbox[c];
-      }
-      R l0 = t_min, l1 = t_incl, r0 = t_min, r1 = t_incl;
-      const bool hl = slab_hit(lb, lb + 3, r.o, inv_d, l0, l1);
-      const bool hr = slab_hit(rb, rb + 3, r.o, inv_d, r0, r1);
-      const bool left_first = hl && (!hr || l0 <= r0);
-      if (hl && hr) {
-        stack[sp * stride] = left_first ? n.right : n.left;
-        stack_t[sp * stride] = entry_bits_below(left_first ? r0 : l0);
-        ++sp;
-      }
-      cur = left_first ? n.left : n.right;
-      if (!(hl || hr)) walking = pop();
-    }
-    if (!walking) break;
-    {
-      const R t_incl = next_up(closest);
-      R t;
-      bool h;
-      if constexpr (sizeof(R) == 4)
-        h = leaf_t_unified(sc, cur, r, inv_d, a, t_min, t_incl, rng, t, cnt);
-      else if (ref_kind(cur) == LEAF_COMPLEX)
-        h = complex_t(sc, ref_index(cur), r, t_min, t_incl, rng, t, cnt);
-      else
-        h = prim_t(sc, cur, r, inv_d, a, t_min, t_incl, t, cnt);
-      if (h) {
-        bool take = t < closest;
-        if (t == closest && best != REF_NONE) take = leaf_rank(sc, cur) < leaf_rank(sc, best);
-        if (take) {
-          closest = t;
-          best = cur;
-        }
-      }
-    }
-    walking = pop();
-    if (!walking) break;
   }
+  template <bool STATS>  // `cur` is an inner node
+  RT_DEV bool node_step(const SceneView<R>& sc, const RayT<R>& r, R t_min, uint32_t* stack, uint16_t* stack_t, uint32_t stride,
+                        Cnt<STATS>& cnt) {
+    cnt.template inc<ST_NODES>(2);
+    const Node2 n = sc.nodes2[cur];
+    const R t_incl = next_up(closest);
+    R lb[6], rb[6];
+    for (int c = 0; c < 6; ++c) {
+      lb[c] = (R)n.lbox[c];
+      rb[c] = (R)n.rbox[c];
+    }
+    R l0 = t_min, l1 = t_incl, r0 = t_min, r1 = t_incl;
+    const bool hl = slab_hit(lb, lb + 3, r.o, inv_d, l0, l1);
+    const bool hr = slab_hit(rb, rb + 3, r.o, inv_d, r0, r1);
+    const bool left_first = hl && (!hr || l0 <= r0);
+    if (hl && hr) {
+      stack[sp * stride] = left_first ? n.right : n.left;
+      stack_t[sp * stride] = entry_bits_below(left_first ? r0 : l0);
+      ++sp;
+    }
+    cur = left_first ? n.left : n.right;
+    if (hl || hr) return true;
+    return pop(stack, stack_t, stride);
+  }
+  template <bool STATS>  // `cur` is a leaf
+  RT_DEV bool leaf_step(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, const uint32_t* stack, const uint16_t* stack_t,
+                        uint32_t stride, Cnt<STATS>& cnt) {
+    const R t_incl = next_up(closest);
+    R t;
+    bool h;
+    if constexpr (sizeof(R) == 4)
+      h = leaf_t_unified(sc, cur, r, inv_d, a, t_min, t_incl, rng, t, cnt);
+    else if (ref_kind(cur) == LEAF_COMPLEX)
+      h = complex_t(sc, ref_index(cur), r, t_min, t_incl, rng, t, cnt);
+    else
+      h = prim_t(sc, cur, r, inv_d, a, t_min, t_incl, t, cnt);
+    if (h) {
+      bool take = t < closest;
+      if (t == closest && best != REF_NONE) take = leaf_rank(sc, cur) < leaf_rank(sc, best);
+      if (take) {
+        closest = t;
+        best = cur;
+      }
+    }
+    return pop(stack, stack_t, stride);
+  }
+};
+// run to completion (A/B form: RT_F64_ORDERED_NO_REFILL)
+template <typename R, bool STATS>
+RT_DEV void traverse_ordered(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, uint32_t* stack, uint16_t* stack_t,
+                             uint32_t stride, R& closest, uint32_t& best, Cnt<STATS>& cnt) {
+  OrderedWalkR<R> w;
+  bool walking = w.start(sc, r);
+  while (walking) {
+    while (walking && !(w.cur & REF_LEAF)) walking = w.node_step(sc, r, t_min, stack, stack_t, stride, cnt);
+    if (!walking) break;
+    walking = w.leaf_step(sc, r, t_min, rng, stack, stack_t, stride, cnt);
+  }
+  closest = w.closest;
+  best = w.best;
 }
 
 // Small scenes (a handful of leaves): test every leaf in BVH left-first DFS order with the

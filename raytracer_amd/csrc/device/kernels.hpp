@@ -1235,7 +1235,7 @@ constexpr uint32_t UNIT_RING = 32;
 template <typename R, bool STATS, int TRAV = TRAV_LINEAR, bool EARLY_EXIT = true, bool NOISE = false>
 __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WAVES : TRAV == TRAV_LEAVES ? RT_LEAVES_MIN_WAVES : (sizeof(R) == 8 ? RT_RENDER_F64_MIN_WAVES : RT_RENDER_MIN_WAVES))
     render_persist_kernel(SceneView<R> sc_in, CameraView<R> cam, RenderArgs a, R* __restrict__ accum, DeviceStats* stats) {
-  constexpr bool LINEAR = TRAV == TRAV_LINEAR, LEAVES = TRAV == TRAV_LEAVES;
+  constexpr bool LINEAR = TRAV == TRAV_LINEAR, LEAVES = TRAV == TRAV_LEAVES, ORDERED = TRAV == TRAV_ORDERED;
   static_assert(TRAV == TRAV_LINEAR || TRAV == TRAV_REFERENCE || TRAV == TRAV_LEAVES || TRAV == TRAV_ORDERED,
                 "leaf list, reference-order or (run to completion) ordered walk");
   extern __shared__ uint32_t lds_stack[];  // TRAV_REFERENCE / TRAV_ORDERED: the walk's stack
@@ -1310,6 +1310,16 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
   Vec3<R> thr, L;
   Rng rng;
   rng.init(a.seed, 0, 0);
+  // TRAV_ORDERED: the walk is a resumable state machine — a lane whose walk is over goes on to its vertex (and its next
+  // ray) while its neighbours keep walking; the wave leaves the step loop once a.refill_eighths / 8 of its lanes wait
+  [[maybe_unused]] bool walking = false;
+  [[maybe_unused]] OrderedWalkR<R> walk;
+  walk.cur = REF_NONE;
+  walk.sp = 0;
+  walk.best = REF_NONE;
+  walk.closest = R(0);
+  walk.a = R(0);
+  walk.inv_d = Vec3<R>(0, 0, 0);
 #ifdef RT_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
@@ -1401,11 +1411,41 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
       alive = true;
     }
     RT_STAMP(2);  // camera ray
+    R t;
+    uint32_t best;
+    if constexpr (ORDERED) {
+      if (!walking) {  // a fresh ray (camera or scattered)
+        rng.begin(rng.slot + 1u);
+        cnt.template inc<ST_RAYS>();
+        walking = walk.start(sc, ray);
+      }
+      RT_STAMP(3);
+      const uint32_t n_active = (uint32_t)__popcll(__ballot(true));  // lanes with a path
+      const uint32_t refill_q = (n_active * a.refill_eighths) >> 3;
+      const uint32_t refill_at = refill_q > 0 ? refill_q : 1u;
+      for (;;) {
+        const uint32_t n_walking = (uint32_t)__popcll(__ballot(walking));
+        if (n_walking == 0 || n_walking + refill_at <= n_active) break;
+        const uint32_t leaves_at = (n_walking >> a.leaf_shift) > 0 ? (n_walking >> a.leaf_shift) : 1u;
+        for (;;) {  // node steps together ...
+          const bool at_node = walking && !(walk.cur & REF_LEAF);
+          const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node));
+          const uint32_t n_walk_now = (uint32_t)__popcll(__ballot(walking));
+          if (n_node == 0 || n_walk_now - n_node >= leaves_at || n_walk_now + refill_at <= n_active) break;
+          if (at_node) walking = walk.node_step(sc, ray, R(0.001), stack, stack_t, (uint32_t)BLOCK, cnt);
+        }
+        // ... then the leaf tests together
+        if (walking && (walk.cur & REF_LEAF))
+          walking = walk.leaf_step(sc, ray, R(0.001), rng, stack, stack_t, (uint32_t)BLOCK, cnt);
+      }
+      RT_STAMP(4);
+      if (walking) continue;  // still on its way: no vertex for this lane in this round
+      t = walk.closest;
+      best = walk.best;
+    } else {
     rng.begin(rng.slot + 1u);  // slot 0 = camera, slot b = the b-th ray of the path (also its depth counter)
     cnt.template inc<ST_RAYS>();
     RT_STAMP(3);  // bounce Philox block
-    R t;
-    uint32_t best;
     if constexpr (LINEAR) {
       if (sc.linear_has_media)  // wave-uniform
         traverse_linear<STATS, true>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
@@ -1413,12 +1453,11 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
         traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
     } else if constexpr (LEAVES) {
       traverse_leaves(sc, ray, R(0.001), rng, t, best, cnt);
-    } else if constexpr (TRAV == TRAV_ORDERED) {
-      traverse_ordered(sc, ray, R(0.001), rng, stack, stack_t, (uint32_t)BLOCK, t, best, cnt);
     } else {
       traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
     }
     RT_STAMP(4);  // leaf-list walk
+    }
     bool cont;
     if (best == REF_NONE) {  // main.rs:104
       cnt.template inc<ST_MISSES>();

@@ -669,6 +669,13 @@ struct rt_scene {
   uint32_t n_nodes = 0;
   bool boxes_conservative = false;               // leaf-list / ordered walks allowed ...
   double safe_t_lo = 0, safe_t_hi = 0;           // ... for cameras whose shutter lies in this window
+  // Some Cube carries a Dielectric.  A ray refracted INTO a cube re-hits it at t_min (Cube::hit reports the running t_min
+  // for a ray that starts inside, hittable.rs:211-228), and the reflection at that vertex leaves through the entry face
+  // after EXACTLY t = t_min in exact arithmetic: `t_max <= t_min` (hittable.rs:224 — and aabb.rs:30 for every box above
+  // the cube) is then decided by the last bit, box by box.  Only the walk that tests the reference's own boxes in the
+  // reference's own order reproduces those decisions, so the f64 kernel — whose contract is the reference's result bit for
+  // bit — keeps the reference-order walk on such scenes (no reference scene has one; tests/sweep_mixed.py found 3 in 4004).
+  bool glass_cube = false;
   SceneSide<float> f32;
   SceneSide<double> f64;
   uint64_t last_redecided = 0;  // rt_primary_redecided
@@ -989,6 +996,8 @@ int rt_scene_create(int device, const rt_scene_desc* d, rt_scene** out) {
   s->n_nodes = d->n_nodes;
   hipError_t e;
   s->boxes_conservative = facts.conservative;
+  for (uint32_t i = 0; i < d->n_cubes; ++i)
+    if (d->cube_material[i] < d->n_materials && d->mat_tag[d->cube_material[i]] == RT_MAT_DIELECTRIC) s->glass_cube = true;
   s->safe_t_lo = facts.t_lo;
   s->safe_t_hi = facts.t_hi;
   std::vector<Node2> tree2;  // the ordered walk's tree: built by the f32 side, shared with the f64 side
@@ -1032,11 +1041,12 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   // f64: leaf-list scenes walk the leaf list too (traverse_leaves: same winners, t and draws as the reference-order
   // walk, no node tests); RT_FLAG_FORCE_BVH / RT_F64_NO_LEAVES=1 keep the reference-order walk (A/B, work counting)
   static const bool f64_no_leaves = getenv("RT_F64_NO_LEAVES") != nullptr;
-  if (f64 && fast_ok && !f64_no_leaves && !s->f64.view.has_noise && s->f64.view.n_leaf_list > 0 && max_depth > 0 && n_samples > 0)
+  const bool f64_fast_ok = f64 && fast_ok && !s->glass_cube;  // (see rt_scene::glass_cube)
+  if (f64_fast_ok && !f64_no_leaves && !s->f64.view.has_noise && s->f64.view.n_leaf_list > 0 && max_depth > 0 && n_samples > 0)
     sh.trav = 3;
   // f64, larger scenes: the ordered walk in f64 (traverse_ordered, persistent form only); RT_F64_NO_ORDERED=1 (A/B)
   static const bool f64_no_ordered = getenv("RT_F64_NO_ORDERED") != nullptr;
-  const bool ordered64 = f64 && sh.trav == 0 && fast_ok && !f64_no_ordered && !s->f64.view.has_noise &&
+  const bool ordered64 = f64_fast_ok && sh.trav == 0 && !f64_no_ordered && !s->f64.view.has_noise &&
                          s->f64.ordered_root != RT_REF_NONE && max_depth > 0 && n_samples > 0;
   if (ordered64) sh.trav = 2;
   uint32_t tx = (w + 15) / 16, ty = (h + 15) / 16;
@@ -1051,6 +1061,13 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   // leaf — measured: shift 1 is +2 % on random_scene / final_scene / 1 M spheres but -8 % at 20 k
   static const char* ls = getenv("RT_LEAF_SHIFT");  // tuning override
   sh.leaf_shift = ls ? (uint32_t)std::min(5, std::max(0, atoi(ls))) : (n_nodes <= 4096 || n_nodes > 65536) ? 1u : 2u;
+  if (ordered64) {
+    // the f64 ordered walk inside the persistent kernel (refill threshold x leaf-phase threshold, ms on C1 / C3 / C4 f64
+    // samples, tools/f64_ordered_tune.sh: 8/8 = run to completion 8.9 / 61.1 / 12.0; 6/8, shift 1: 7.8 / 53.7 / 8.5;
+    // 4/8, shift 1: 8.1 / 58.1 / 8.4; shift 0 or 2: 3-70 % slower)
+    if (!re) sh.refill_eighths = 6u;
+    if (!ls) sh.leaf_shift = 1u;
+  }
   static const char* xc = getenv("RT_XCD_CHUNK");
   sh.xcd_chunk = xc ? (uint32_t)std::max(0, atoi(xc)) : 1u;
   static const char* tb = getenv("RT_TILE_BAND");

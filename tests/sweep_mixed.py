@@ -30,12 +30,15 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2]) + 1):
             if rel.size and (np.quantile(rel, 0.995) > 1e-5 or rel.max() > 1e-3): msgs.append(f"f32 t rel p99.5 {np.quantile(rel, 0.995):.2g} max {rel.max():.2g}")
             fh = f[0] != 0xFFFFFFFF
             if not (np.array_equal(a[0], f[0]) and np.array_equal(a[1][fh], f[1][fh]) and np.array_equal(a[2][fh], f[2][fh])): msgs.append(f"fast walk differs: ids {(a[0] != f[0]).sum()} t {(a[1][fh] != f[1][fh]).sum()}")
-        g, gst = ds.render(W, h, 4, 10, seed=seed, stats=True, f64=True)
         o, ocnt, _ = os_.render(W, h, 4, 10, seed=seed)
-        if (np.isfinite(o) == np.isfinite(g)).mean() < 1.0: msgs.append(f"finite masks differ {(np.isfinite(o) != np.isfinite(g)).sum()}")
-        fin = np.isfinite(o) & np.isfinite(g)
-        err = np.abs(g - o)[fin] / (1 + np.abs(o[fin]))
-        if (err > 1e-9).mean() > 1e-3: msgs.append(f"f64 image differs in {(err > 1e-9).mean():.4f}")
+        for force_bvh in (True, False):  # the reference-order f64 walk, then the default one (leaf list / ordered walk)
+            tag = "f64 ref-order" if force_bvh else "f64 default"
+            g, gst = ds.render(W, h, 4, 10, seed=seed, stats=True, f64=True, force_bvh=force_bvh)
+            if (np.isfinite(o) == np.isfinite(g)).mean() < 1.0: msgs.append(f"{tag}: finite masks differ {(np.isfinite(o) != np.isfinite(g)).sum()}")
+            fin = np.isfinite(o) & np.isfinite(g)
+            err = np.abs(g - o)[fin] / (1 + np.abs(o[fin]))
+            if (err > 1e-9).mean() > 1e-3: msgs.append(f"{tag}: image differs in {(err > 1e-9).mean():.4f}")
+            if gst["rays"] != ocnt["rays"] and abs(gst["rays"] - ocnt["rays"]) > 1e-3 * ocnt["rays"]: msgs.append(f"{tag}: rays {gst['rays']} vs {ocnt['rays']}")
         for d in (3,):
             x, _ = ds.render(W, h, 64, d, seed=seed)
             y, _ = ds.render(W, h, 64, d, seed=seed, f64=True)

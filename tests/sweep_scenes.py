@@ -46,17 +46,21 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2]) + 1):
             fh = f[0] != 0xFFFFFFFF
             if not (np.array_equal(a[0], f[0]) and np.array_equal(a[1][fh], f[1][fh])):
                 msgs.append(f"fast walk differs: ids {(a[0] != f[0]).sum()}")
-        g, gst = ds.render(W, h, 4, 12, seed=seed, stats=True, f64=True)
         o, ocnt, _ = os_.render(W, h, 4, 12, seed=seed)
-        if (np.isfinite(o) != np.isfinite(g)).any():
-            msgs.append(f"finite masks differ {(np.isfinite(o) != np.isfinite(g)).sum()}")
-        fin = np.isfinite(o) & np.isfinite(g)
-        err = np.abs(g - o)[fin] / (1 + np.abs(o[fin]))
-        if (err > 1e-9).mean() > 1e-3:
-            msgs.append(f"f64 image differs in {(err > 1e-9).mean():.4f}")
-        for k in ("rays", "nodes_visited", "sphere_tests", "closest_hits", "misses"):
-            if abs(gst[k] - ocnt[k]) > 1e-3 * max(1, ocnt[k]):
-                msgs.append(f"f64 counter {k}: {gst[k]} vs {ocnt[k]}")
+        # both f64 walks: the reference-order walk (every work counter is the oracle's), then the default (ordered walk of
+        # the SAH tree / leaf list: same paths, so the same image and outcome counters; traversal counters differ)
+        for force_bvh in (True, False):
+            tag = "f64 ref-order" if force_bvh else "f64 default"
+            g, gst = ds.render(W, h, 4, 12, seed=seed, stats=True, f64=True, force_bvh=force_bvh)
+            if (np.isfinite(o) != np.isfinite(g)).any():
+                msgs.append(f"{tag}: finite masks differ {(np.isfinite(o) != np.isfinite(g)).sum()}")
+            fin = np.isfinite(o) & np.isfinite(g)
+            err = np.abs(g - o)[fin] / (1 + np.abs(o[fin]))
+            if (err > 1e-9).mean() > 1e-3:
+                msgs.append(f"{tag}: image differs in {(err > 1e-9).mean():.4f}")
+            for k in ("rays", "closest_hits", "misses") + (("nodes_visited", "sphere_tests") if force_bvh else ()):
+                if abs(gst[k] - ocnt[k]) > 1e-3 * max(1, ocnt[k]):
+                    msgs.append(f"{tag}: counter {k}: {gst[k]} vs {ocnt[k]}")
         x, sx = ds.render(W, h, 64, 4, seed=seed, stats=True)
         y, _ = ds.render(W, h, 64, 4, seed=seed, f64=True)
         z, sz = ds.render(W, h, 64, 4, seed=seed, stats=True, force_bvh=True)

@@ -445,6 +445,34 @@ def test_f64_persistent_kernel_on_ragged_images_accumulates_on_the_device(size):
     np.testing.assert_allclose(got[fin], o[fin], rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("size", [(2, 2), (37, 23), (130, 3), (49, 33)])
+@pytest.mark.parametrize("spp", [1, 3, 11])
+def test_f64_ordered_walk_on_ragged_images_and_odd_sample_counts(size, spp):
+    """The f64 kernel on a BVH-bound scene (ordered walk as a resumable state machine inside the persistent kernel: lanes
+    whose walk is over go on to their vertex while their neighbours keep walking): ragged images, sample counts that are
+    no multiple of the unit size, depths 1 and 50 — the oracle's sums and ray count, and equal to the reference-order f64
+    walk of the same tree, also on top of an existing accumulator."""
+    import torch
+    import oracle_ffi as O
+    import raytracer_amd as R
+    w, h = size
+    hs = R.HostScene(7, w / h, n=3000)
+    ds = R.DeviceScene(hs, 0)
+    orc = O.OracleScene(7, w / h, n=3000)
+    for depth in (1, 50):
+        o, ocnt, _ = orc.render(w, h, spp, depth, seed=4, sample_offset=2)
+        a, sa = ds.render(w, h, spp, depth, seed=4, sample_offset=2, stats=True, f64=True)
+        b, sb = ds.render(w, h, spp, depth, seed=4, sample_offset=2, stats=True, f64=True, force_bvh=True)
+        assert sa["rays"] == sb["rays"] == ocnt["rays"]
+        fin = np.isfinite(o)
+        assert (np.isfinite(a) == fin).all() and (np.isfinite(b) == fin).all()
+        np.testing.assert_allclose(a[fin], o[fin], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(a[fin], b[fin], rtol=1e-12, atol=1e-12)
+    acc = torch.full((h, w, 3), 2.0, dtype=torch.float64, device="cuda:0")
+    ds.render_device(acc.data_ptr(), w, h, spp, 50, seed=4, sample_offset=2, accumulate=True, f64=True)
+    np.testing.assert_allclose(acc.cpu().numpy()[fin], (a + 2.0)[fin], rtol=1e-12, atol=1e-12)
+
+
 def test_back_face_of_an_emitter_still_multiplies_its_zero_up_the_path():
     """material.rs:118-126 + main.rs:93-97: a light hit from behind emits Color::new(), and every caller up the
     recursion still multiplies that zero into attenuation * scattering_pdf / pdf_value — NaN where a vertex had

@@ -33,6 +33,12 @@ def main():
         hs = R.HostScene(scene, asp, n=n, texels=earth)
         ds = R.DeviceScene(hs, 0)
         out = {}
+        if os.environ.get("ONLY_ORDERED"):  # tuning runs: time the default walk only
+            acc = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+            ds.render_device(acc.data_ptr(), w, h, 1, 50, f64=True)
+            ms = min(ds.render_device(acc.data_ptr(), w, h, spp, 50, seed=5, f64=True)["kernel_ms"] for _ in range(3))
+            print(f"{name} {ms:.2f} ms", flush=True)
+            continue
         for label, force in (("ordered", False), ("reference", True)):
             acc = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
             ds.render_device(acc.data_ptr(), w, h, 1, 50, f64=True, force_bvh=force)
