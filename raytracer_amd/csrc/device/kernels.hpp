@@ -539,6 +539,7 @@ struct RenderArgs {
   uint32_t wave_tiles_x, wave_tiles, total_units;
   uint32_t leaf_shift;  // refill kernel: run the leaf tests once (walking lanes >> leaf_shift) lanes wait at a leaf
   uint32_t direct_accum;  // units kernel: no LDS accumulators, finished samples go to the image by float atomics
+  uint32_t unit_prefetch; // render_persist_kernel: units a wave draws ahead of need per visit of the global counter (< UNIT_RING)
   uint32_t xcd_chunk;   // render_kernel, refill kernel: block_slot's mode
   uint32_t tile_band;   // refill kernel: band_order's band height in tiles
   uint64_t seed;
@@ -1221,6 +1222,19 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_units_kerne
 // on different waves).  Same paths and draws as render_kernel: a sample's Philox stream is keyed by
 // (pixel, sample), not by who renders it.
 constexpr uint32_t UNIT_RING = 32;
+// LDS words that the lanes of ONE wave hand to each other (the unit ring): plain ds_read / ds_write — a wave's LDS
+// operations execute in program order, so all that is needed is that the compiler keeps them in that order and does
+// not cache them in registers (relaxed atomics at wavefront scope + a wavefront-scope fence: no instruction is emitted
+// for either).  Declared `volatile`, the same words were accessed through FLAT instructions with system-scope
+// coherence bits and a full vmcnt(0) wait each — in the hand-over block that some lane of a wave enters in every
+// second iteration of the f64 kernel.
+RT_DEV uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+RT_DEV void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+RT_DEV void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 #ifndef RT_PERSIST_MIN_WAVES
 #define RT_PERSIST_MIN_WAVES 6  // measured (after sphere_roots stopped the f64 hoist): 4: 54.2, 5: 61.1, 6 (80 VGPRs, 32 B scratch): 65.3, 7: 63.1 Grays/s
 #endif
@@ -1254,6 +1268,29 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
   __shared__ uint32_t s_leaf_list[LEAVES ? LIN_MAX_LEAVES : 1];
   // ... and the camera (24 doubles that are read once per sample): in LDS they cost no scalar registers between samples
   __shared__ alignas(16) unsigned char s_cam_raw[LEAVES ? sizeof(CameraView<R>) : 16];
+  // ... and, per lane, the winning complex leaf's mapped ray (6 reals, column-major by lane): computed by the walk, read
+  // by the hit record (see traverse_leaves)
+#ifdef RT_LEAF_STASH
+  __shared__ R s_stash_all[LEAVES ? 6 * BLOCK : 1];
+  [[maybe_unused]] R* stash = LEAVES ? s_stash_all + threadIdx.x : nullptr;
+#else
+  [[maybe_unused]] R* stash = nullptr;
+#endif
+  // f64 leaf-list form: the lane's running pixel sum lives in LDS (3 reals, column-major by lane), not in 6 vector
+  // registers the walk would spill; it is touched once per finished sample.  (Not the stack-walking forms: their LDS
+  // decides how many workgroups a CU holds — 10^6 spheres in f64: 116.5 -> 130.9 ms with these 6 KB.)
+#ifndef RT_NO_F64_ACC_LDS
+  constexpr bool ACC_LDS = sizeof(R) == 8 && LEAVES;
+#else
+  constexpr bool ACC_LDS = false;
+#endif
+  __shared__ R s_acc_all[ACC_LDS ? 3 * BLOCK : 1];
+  [[maybe_unused]] R* s_acc = s_acc_all + (ACC_LDS ? threadIdx.x : 0u);
+  if constexpr (ACC_LDS) {
+    s_acc[0] = R(0);
+    s_acc[BLOCK] = R(0);
+    s_acc[2 * BLOCK] = R(0);
+  }
   SceneView<R> sc = sc_in;
   if constexpr (LEAVES) {
     if (threadIdx.x == 0) *reinterpret_cast<CameraView<R>*>(s_cam_raw) = cam;
@@ -1274,9 +1311,9 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
     sc.op_tag = s_op_tag;
     sc.leaf_list = s_leaf_list;
   }
-  __shared__ volatile uint32_t s_unit_xy[BLOCK / 64][UNIT_RING];  // tile origin x | y << 16
-  __shared__ volatile uint32_t s_unit_k[BLOCK / 64][UNIT_RING];   // which sample range of the launch
-  __shared__ uint32_t s_red[BLOCK / 64][2];                       // wave-wide max / min scratch
+  __shared__ uint32_t s_unit_xy[BLOCK / 64][UNIT_RING];  // tile origin x | y << 16
+  __shared__ uint32_t s_unit_k[BLOCK / 64][UNIT_RING];   // which sample range of the launch
+  __shared__ uint32_t s_red[BLOCK / 64][2];              // wave-wide min scratch
   {
     const uint32_t n_l = sc.n_lights < LDS_MAX_LIGHTS ? sc.n_lights : LDS_MAX_LIGHTS;
     constexpr uint32_t LW = sizeof(Light<R>) / 4;
@@ -1300,14 +1337,14 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
   Cnt<STATS> cnt;
   cnt.clear();
   uint32_t nonfinite = 0;
-  Vec3<R> acc;
+  [[maybe_unused]] Vec3<R> acc;
   uint32_t list_len = 0;    // wave-uniform: units this wave has drawn so far
   bool exhausted = false;   // wave-uniform: the global counter has run dry
   uint32_t ui = 0xFFFFFFFFu;  // this lane's position in the wave's list (none yet)
   uint32_t s = 0, s_end = 0, px = 0, py = 0;
   bool have_pixel = false, lane_done = false, alive = false;
   RayT<R> ray;
-  Vec3<R> thr, L;
+  Vec3<R> thr;
   Rng rng;
   rng.init(a.seed, 0, 0);
   // TRAV_ORDERED: the walk is a resumable state machine — a lane whose walk is over goes on to its vertex (and its next
@@ -1327,48 +1364,64 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
 
   for (;;) {
     RT_STAMP(0);  // loop tail + re-convergence
-    // (0) lanes that have finished their pixel's samples of a unit move on to the wave's next unit
+    // (0) lanes that have finished their pixel's samples of a unit move on to the wave's next unit.  The common case is
+    // lane-local: the list already holds the next entry (two LDS reads).  Only when a lane has run to the END of the
+    // list does the wave act together: it draws the missing unit plus UNIT_PREFETCH more with ONE atomic on the global
+    // counter (consecutive units; lane i fills entry i), so that this wave-wide part runs once per UNIT_PREFETCH + 1
+    // hand-overs instead of at every one (with 16-sample units some lane of the wave is at a hand-over in every
+    // second iteration).  Units drawn ahead are at most UNIT_PREFETCH per wave: a fraction of a millisecond of work
+    // at the launch's end.
     const bool needy = !alive && s == s_end && !lane_done;
     if (__ballot(needy)) {  // wave-uniform
       if (needy && have_pixel) {
         R* out = accum + 3ull * (py * a.width + px);
-        atomicAdd(out + 0, acc.x);
-        atomicAdd(out + 1, acc.y);
-        atomicAdd(out + 2, acc.z);
-        acc = Vec3<R>(0, 0, 0);
+        if constexpr (ACC_LDS) {
+          atomicAdd(out + 0, s_acc[0]);
+          atomicAdd(out + 1, s_acc[BLOCK]);
+          atomicAdd(out + 2, s_acc[2 * BLOCK]);
+          s_acc[0] = R(0);
+          s_acc[BLOCK] = R(0);
+          s_acc[2 * BLOCK] = R(0);
+        } else {
+          atomicAdd(out + 0, acc.x);
+          atomicAdd(out + 1, acc.y);
+          atomicAdd(out + 2, acc.z);
+          acc = Vec3<R>(0, 0, 0);
+        }
         have_pixel = false;
       }
-      const uint32_t leader = (uint32_t)__builtin_ctzll(__ballot(1));
-      if (lane == leader) {
-        s_red[wave][0] = 0u;
-        s_red[wave][1] = 0xFFFFFFFFu;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (needy) atomicMax(&s_red[wave][0], ui + 2u);  // the list must reach index ui + 1
-      if (!lane_done) atomicMin(&s_red[wave][1], ui + 1u);  // the oldest entry anybody may still read
-      __builtin_amdgcn_wave_barrier();
-      const uint32_t want = ((volatile uint32_t*)s_red[wave])[0];
-      const uint32_t oldest = ((volatile uint32_t*)s_red[wave])[1];
-      while (list_len < want && !exhausted && list_len - oldest < UNIT_RING) {  // wave-uniform
-        uint32_t u = 0;
-        if (lane == leader) u = atomicAdd(&stats->unit_counter, 1u);
-        u = __shfl(u, (int)leader, 64);
-        if (u >= a.total_units) {
-          exhausted = true;
-          break;
+      // a needy lane stands at ui and wants entry ui + 1 <= list_len: the list is short for it iff ui + 1 == list_len
+      if (__ballot(needy && ui + 1u >= list_len) && !exhausted) {  // wave-uniform
+        // the oldest entry anybody may still read: entries before min(ui + 1) over the unfinished lanes are dead
+        const uint32_t leader = (uint32_t)__builtin_ctzll(__ballot(1));
+        if (lane == leader) lds_store(&s_red[wave][1], 0xFFFFFFFFu);
+        wave_lds_fence();
+        if (!lane_done) atomicMin(&s_red[wave][1], ui + 1u);
+        wave_lds_fence();
+        const uint32_t oldest = __builtin_amdgcn_readfirstlane(lds_load(&s_red[wave][1]));
+        const uint32_t room = UNIT_RING - (list_len - oldest);  // (list_len - oldest <= UNIT_RING always)
+        uint32_t n_new = 1u + a.unit_prefetch < room ? 1u + a.unit_prefetch : room;
+        if (n_new) {
+          uint32_t u0 = 0;
+          if (lane == leader) u0 = atomicAdd(&stats->unit_counter, n_new);
+          u0 = __shfl(u0, (int)leader, 64);
+          if (u0 + n_new >= a.total_units) {
+            exhausted = true;
+            n_new = u0 < a.total_units ? a.total_units - u0 : 0u;
+          }
+          if (lane < n_new) {
+            const uint32_t u = u0 + lane, tile = u % a.wave_tiles, e = (list_len + lane) % UNIT_RING;
+            lds_store(&s_unit_xy[wave][e], ((tile % a.wave_tiles_x) * 8u) | (((tile / a.wave_tiles_x) * 8u) << 16));
+            lds_store(&s_unit_k[wave][e], u / a.wave_tiles);
+          }
+          list_len += n_new;
+          wave_lds_fence();
         }
-        if (lane == leader) {
-          const uint32_t tile = u % a.wave_tiles;
-          s_unit_xy[wave][list_len % UNIT_RING] = ((tile % a.wave_tiles_x) * 8u) | (((tile / a.wave_tiles_x) * 8u) << 16);
-          s_unit_k[wave][list_len % UNIT_RING] = u / a.wave_tiles;
-        }
-        ++list_len;
       }
-      __builtin_amdgcn_wave_barrier();
       if (needy) {
         if (ui + 1u < list_len) {
           ++ui;
-          const uint32_t xy = s_unit_xy[wave][ui % UNIT_RING], k = s_unit_k[wave][ui % UNIT_RING];
+          const uint32_t xy = lds_load(&s_unit_xy[wave][ui % UNIT_RING]), k = lds_load(&s_unit_k[wave][ui % UNIT_RING]);
           px = (xy & 0xFFFFu) + (lane & 7u);
           py = (xy >> 16) + (lane >> 3);
           // s, s_end: GLOBAL sample indices (what the Philox counter takes), so that the sample in flight and the
@@ -1402,12 +1455,14 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
         u = rdiv((R)px + ju, (R)(a.width - 1));
         v = rdiv((R)(a.height - py - 1) + jv, (R)(a.height - 1));
       }
-      if constexpr (LEAVES)
+      if constexpr (LEAVES) {
         ray = camera_ray(*reinterpret_cast<const CameraView<R>*>(s_cam_raw), u, v, rng);
-      else
+#ifndef RT_KEEP_LEAVES_TIME
+        ray.time = R(0);  // leaf-list scenes hold no moving sphere (rt_scene_create): the shutter time is drawn, never read
+#endif
+      } else
         ray = camera_ray(cam, u, v, rng);
       thr = Vec3<R>(1, 1, 1);
-      L = Vec3<R>(0, 0, 0);
       alive = true;
     }
     RT_STAMP(2);  // camera ray
@@ -1443,7 +1498,14 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
       t = walk.closest;
       best = walk.best;
     } else {
-    rng.begin(rng.slot + 1u);  // slot 0 = camera, slot b = the b-th ray of the path (also its depth counter)
+    // slot 0 = camera, slot b = the b-th ray of the path (also its depth counter).  No walk reads the slot's block (a
+    // medium's draw is keyed by the slot's counter alone): with RT_LATE_BLOCK it is generated after the walk, for the
+    // lanes that hit something, and its four words are not live across the walk
+#ifndef RT_NO_LATE_BLOCK
+    rng.set_slot(rng.slot + 1u);
+#else
+    rng.begin(rng.slot + 1u);
+#endif
     cnt.template inc<ST_RAYS>();
     RT_STAMP(3);  // bounce Philox block
     if constexpr (LINEAR) {
@@ -1452,12 +1514,15 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
       else
         traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
     } else if constexpr (LEAVES) {
-      traverse_leaves(sc, ray, R(0.001), rng, t, best, cnt);
+      traverse_leaves(sc, ray, R(0.001), rng, t, best, cnt, stash, (uint32_t)BLOCK);
     } else {
       traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
     }
     RT_STAMP(4);  // leaf-list walk
     }
+    // A path's radiance is set ONCE, at its last vertex (an emitter, a miss, the depth limit: main.rs:73-75, 101, 104) —
+    // up to there ray_color's sum is the zero it starts from, so it need not be carried from vertex to vertex.
+    Vec3<R> L(0, 0, 0);
     bool cont;
     if (best == REF_NONE) {  // main.rs:104
       cnt.template inc<ST_MISSES>();
@@ -1470,10 +1535,16 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
       if constexpr (LINEAR) {
         lin_hit_record(sc, s_lin + best * LIN_DWORDS, ray, t, h, mat);
       } else {
-        make_hit_record(sc, best, ray, t, false, h);
+        if constexpr (LEAVES)
+          make_hit_record(sc, best, ray, t, false, h, stash, (uint32_t)BLOCK);
+        else
+          make_hit_record(sc, best, ray, t, false, h);
         mat = sc.materials[h.material];
       }
       RT_STAMP(5);  // hit record
+#ifndef RT_NO_LATE_BLOCK
+      if constexpr (!ORDERED) rng.refill();
+#endif
       cont = shade<R, STATS, NOISE>(sc, lights, mat, h, ray, thr, L, rng, cnt);
     }
     RT_STAMP(6);  // shade (or miss)
@@ -1485,7 +1556,12 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
     if (!cont) {
       const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
       if (!fin) ++nonfinite;
-      if (fin || sizeof(R) == 8) acc = acc + L;  // (the f64 audit kernel lets it poison the pixel like the reference does)
+      if constexpr (ACC_LDS) {  // (the f64 kernel lets a non-finite sample poison the pixel like the reference does)
+        s_acc[0] += L.x;
+        s_acc[BLOCK] += L.y;
+        s_acc[2 * BLOCK] += L.z;
+      } else if (fin || sizeof(R) == 8)
+        acc = acc + L;
       alive = false;
       ++s;
     }

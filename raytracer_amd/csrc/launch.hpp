@@ -23,6 +23,7 @@ struct LaunchShape {
   uint32_t tile_band = 1;       // refill kernel: see RenderArgs::tile_band
   // leaf-list scenes, persistent kernel (render_persist_kernel): 0 = off
   uint32_t unit_samples = 0, wave_tiles_x = 0, wave_tiles = 0, total_units = 0;
+  uint32_t unit_prefetch = 0;  // render_persist_kernel: units a wave draws ahead of need per visit of the global counter
   int trav;              // 0 reference-order BVH walk, 1 leaf list, 2 ordered BVH walk (f32 only for 1, 2)
 };
 

@@ -39,6 +39,7 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   a.stack_depth = shape.stack_depth;
   a.refill_eighths = shape.refill_eighths;
   a.unit_samples = shape.unit_samples;
+  a.unit_prefetch = shape.unit_prefetch;
   a.wave_tiles_x = shape.wave_tiles_x;
   a.wave_tiles = shape.wave_tiles;
   a.total_units = shape.total_units;

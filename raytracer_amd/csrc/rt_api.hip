@@ -1030,6 +1030,17 @@ int check_camera(const rt_camera* cam) {
   return RT_OK;
 }
 
+// render_persist_kernel: how many units a wave draws AHEAD of need at each visit of the global counter.  Units held by
+// a wave when the counter runs dry are the launch's tail, so only launches with hundreds of units per wave draw ahead
+// (measured, f64 Cornell 1024^2: 256 spp = 32 units per wave, prefetch 0 / 1 / 3 / 7: 113 / 118 / 128 / 136 ms; 1024 spp
+// = 128 per wave, 0 / 3: 402 / 400 ms).  RT_UNIT_PREFETCH overrides.
+static uint32_t persist_prefetch(uint64_t units, uint32_t workgroups) {
+  static const char* up = getenv("RT_UNIT_PREFETCH");
+  if (up) return (uint32_t)std::min(31, std::max(0, atoi(up)));
+  const uint64_t per_wave = units / std::max<uint64_t>(1, 4ull * workgroups);
+  return per_wave >= 256 ? 3u : 0u;
+}
+
 LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_samples, bool f32_fast = false,
                        const rt_camera* cam = nullptr, uint32_t max_depth = 0, bool f64 = false) {
   LaunchShape sh;
@@ -1106,6 +1117,7 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   // (render_persist_kernel).  Off for max_depth 0 (handled by render_kernel) and with RT_LINEAR_NO_PERSIST (A/B).
   static const bool no_persist = getenv("RT_LINEAR_NO_PERSIST") != nullptr || getenv("RT_LINEAR_SORTED") != nullptr;
   static const char* us = getenv("RT_UNIT_SAMPLES");
+  sh.unit_prefetch = 0;  // set below, once the launch's unit count is known
   if (sh.trav == 1 && !no_persist && max_depth > 0) {
     // unit size: large enough to amortise the hand-over (measured optimum 256 at 4096 spp, 64 at 256 spp),
     // small enough that the launch has many units per worker
@@ -1118,6 +1130,7 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
       sh.total_units = (uint32_t)units;
       sh.tiles = (uint32_t)std::min<uint64_t>((units + 3) / 4, 256u * 8u);  // workgroups: at most 8 per CU can be resident
       sh.splits = 1;
+      sh.unit_prefetch = persist_prefetch(units, sh.tiles);
     } else {
       sh.unit_samples = 0;
     }
@@ -1139,6 +1152,7 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
       sh.total_units = (uint32_t)units;
       sh.tiles = (uint32_t)std::min<uint64_t>((units + 3) / 4, 256u * 8u);
       sh.splits = 1;
+      sh.unit_prefetch = persist_prefetch(units, sh.tiles);
     } else {
       sh.unit_samples = 0;
       sh.trav = 0;  // (the leaf-list and ordered f64 forms exist as persistent kernels only)
