@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : (size
     const uint32_t s_end = (uint32_t)(((uint64_t)a.n_samples * (my_split + 1)) / a.splits);
     bool alive = false;
     RayT<R> ray;
-    Vec3<R> thr, L;
+    Vec3<R> thr;
     uint32_t depth_left = 0, slot = 0;
     Rng rng;
     rng.init(a.seed, pixel, 0);
@@ -616,7 +616,6 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : (size
         R v = rdiv((R)(a.height - py - 1) + jv, (R)(a.height - 1));  // main.rs:162-163
         ray = camera_ray(cam, u, v, rng);
         thr = Vec3<R>(1, 1, 1);
-        L = Vec3<R>(0, 0, 0);
         depth_left = a.max_depth;
         slot = 1;
         alive = true;
@@ -652,6 +651,7 @@ __global__ void __launch_bounds__(BLOCK, TRAV == 1 ? RT_LINEAR_MIN_WAVES : (size
         traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
       }
       RT_STAMP(3);
+      Vec3<R> L(0, 0, 0);  // set once, at the path's last vertex (see render_persist_kernel)
       bool cont;
       if (best == REF_NONE) {  // main.rs:104
         cnt.template inc<ST_MISSES>();
@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
   bool alive = false, walking = false;
   uint32_t lp = lane;  // the pixel of the job in flight (0..63 within the tile)
   RayT<R> ray;
-  Vec3<R> thr, L;
+  Vec3<R> thr;
   uint32_t depth_left = 0, slot = 0;
   Rng rng;
   rng.init(a.seed, 0, 0);
@@ -817,7 +817,6 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
             R v = rdiv((R)(a.height - jy - 1) + jv, (R)(a.height - 1));  // main.rs:162-163
             ray = camera_ray(cam, u, v, rng);
             thr = Vec3<R>(1, 1, 1);
-            L = Vec3<R>(0, 0, 0);
             depth_left = a.max_depth;
             slot = 1;
             alive = true;
@@ -861,6 +860,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_refill_kern
     RT_STAMP(5);
     // (3) lanes whose walk is over: one vertex of ray_color (main.rs:77-104)
     if (!walking && alive) {
+      Vec3<R> L(0, 0, 0);  // set once, at the path's last vertex (see render_persist_kernel)
       bool cont;
       if (walk.best == REF_NONE) {  // main.rs:104
         cnt.template inc<ST_MISSES>();
@@ -991,7 +991,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_units_kerne
   bool alive = false, walking = false;
   uint32_t lp = lane;  // pixel (0..63 within its unit's tile) | unit parity << 6 of the job in flight
   RayT<R> ray;
-  Vec3<R> thr, L;
+  Vec3<R> thr;
   uint32_t depth_left = 0, slot = 0;
   Rng rng;
   rng.init(a.seed, 0, 0);
@@ -1083,7 +1083,6 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_units_kerne
             R v = rdiv((R)(a.height - jy - 1) + jv, (R)(a.height - 1));  // main.rs:162-163
             ray = camera_ray(cam, u, v, rng);
             thr = Vec3<R>(1, 1, 1);
-            L = Vec3<R>(0, 0, 0);
             depth_left = a.max_depth;
             slot = 1;
             alive = true;
@@ -1101,7 +1100,13 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_units_kerne
       }
     }
     if (!walking && alive) {
+      // (no walk reads the slot's block — a medium's draw is keyed by the slot's counter alone — so it is generated
+      // after the walk, before the vertex: its words are not live while the lane walks)
+#ifndef RT_NO_LATE_BLOCK
+      rng.set_slot(slot);
+#else
       rng.begin(slot);
+#endif
       cnt.template inc<ST_RAYS>();
       walking = walk.start(sc, ray);
     }
@@ -1142,6 +1147,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_units_kerne
     // (3) lanes whose walk is over: one vertex of ray_color (main.rs:77-104)
     bool finished = false;
     if (!walking && alive) {
+      Vec3<R> L(0, 0, 0);  // set once, at the path's last vertex (see render_persist_kernel)
       bool cont;
       if (walk.best == REF_NONE) {  // main.rs:104
         cnt.template inc<ST_MISSES>();
@@ -1153,6 +1159,9 @@ __global__ void __launch_bounds__(BLOCK, RT_REFILL_MIN_WAVES) render_units_kerne
         make_hit_record(sc, walk.best, ray, walk.closest, false, h);
         const Material<R> mat = sc.materials[h.material];
         RT_STAMP(7);
+#ifndef RT_NO_LATE_BLOCK
+        rng.refill();
+#endif
         cont = shade(sc, lights, mat, h, ray, thr, L, rng, cnt);
       }
       ++slot;
