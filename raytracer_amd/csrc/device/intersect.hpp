@@ -584,8 +584,18 @@ struct OrderedWalk {
     for (;;) {
       if (sp == 0) return false;
       --sp;
+#ifndef RT_POP_SPLIT_READS
+      // both halves of the entry are requested together (one LDS round trip per pop; left to itself the compiler
+      // reads the reference only after the distance has passed the test: two dependent round trips)
+      uint32_t c = stack[sp * stride];
+      uint32_t tb = stack_t[sp * stride];
+      asm volatile("" : "+v"(c), "+v"(tb));
+      cur = c;
+      if (!(entry_float((uint16_t)tb) > closest)) return true;
+#else
       cur = stack[sp * stride];
       if (!(entry_float(stack_t[sp * stride]) > closest)) return true;
+#endif
     }
   }
 
@@ -665,8 +675,11 @@ template <typename R> struct OrderedWalkR {
     for (;;) {
       if (sp == 0) return false;
       --sp;
-      cur = stack[sp * stride];
-      if (!((R)OrderedWalk::entry_float(stack_t[sp * stride]) > closest)) return true;
+      uint32_t c = stack[sp * stride];  // (both halves requested together: see OrderedWalk::pop)
+      uint32_t tb = stack_t[sp * stride];
+      asm volatile("" : "+v"(c), "+v"(tb));
+      cur = c;
+      if (!((R)OrderedWalk::entry_float((uint16_t)tb) > closest)) return true;
     }
   }
   template <bool STATS>  // `cur` is an inner node
