@@ -1584,6 +1584,315 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
   if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&stats->v[ST_NONFINITE], (unsigned long long)nf);
 }
 
+// Leaf-list scenes, jobs NOT tied to lanes and camera rays generated A WAVE AT A TIME (render_queue_kernel; the default
+// for TRAV_LINEAR in f32 and TRAV_LEAVES in f64 unless RT_NO_QUEUE is set).
+//
+// In render_persist_kernel a lane owns a pixel, so in every iteration of the bounce loop the wave runs Camera::get_ray
+// (a Philox block, the jitter, the ray) for the lanes whose path has just ended — 41 % of them in the f32 Cornell
+// kernel (2.43 rays per sample), 19 % in f64 (5.13): the camera code, a tenth of the kernel's instructions, runs at
+// that lane utilisation.  Here a wave cuts its unit (8x8 tile x unit_samples samples) into BATCHES of one sample of
+// all 64 pixels; a batch's 64 camera rays are generated by all 64 lanes together (lane i = pixel i: full lanes) into a
+// wave-private LDS queue, and a lane whose path has ended pops the next ray from the queue (a few LDS reads), whatever
+// pixel it belongs to.  A finished sample is added to its pixel's sum in LDS (two units may be open: a job carries its
+// unit's parity; a unit's sums go to the image by atomics when its last job finishes; if a third unit is needed while
+// the oldest still has paths in flight, that unit is closed early and its stragglers — ORPHANS — add their sample to
+// the image themselves: render_units_kernel's scheme).  Same paths and draws as the other forms: a sample's Philox
+// streams are keyed by (pixel, sample), not by the lane that renders it; only the order of a pixel's sum changes.
+#ifndef RT_QUEUE_F32_MIN_WAVES
+#define RT_QUEUE_F32_MIN_WAVES 6
+#endif
+#ifndef RT_QUEUE_F64_MIN_WAVES
+#define RT_QUEUE_F64_MIN_WAVES 4
+#endif
+template <typename R, bool STATS, int TRAV, bool EARLY_EXIT>
+__global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? RT_QUEUE_F32_MIN_WAVES : RT_QUEUE_F64_MIN_WAVES)
+    render_queue_kernel(SceneView<R> sc_in, CameraView<R> cam_in, RenderArgs a, R* __restrict__ accum, DeviceStats* stats) {
+  constexpr bool LINEAR = TRAV == TRAV_LINEAR, LEAVES = TRAV == TRAV_LEAVES;
+  static_assert(LINEAR || LEAVES, "leaf-list forms only");
+  static_assert(!LINEAR || sizeof(R) == 4, "the LDS leaf records are f32");
+  __shared__ Light<R> s_lights[LDS_MAX_LIGHTS];
+  __shared__ float s_lin[LINEAR ? LIN_MAX_LEAVES * LIN_DWORDS : 1];
+  __shared__ Real4<R> s_spheres[LEAVES ? STAGE_MAX_SPHERES : 1];
+  __shared__ Cube<R> s_cubes[LEAVES ? STAGE_MAX_CUBES : 1];
+  __shared__ Complex s_complexes[LEAVES ? STAGE_MAX_COMPLEXES : 1];
+  __shared__ Op<R> s_ops[LEAVES ? STAGE_MAX_OPS : 1];
+  __shared__ uint32_t s_op_tag[LEAVES ? STAGE_MAX_OPS : 1];
+  __shared__ uint32_t s_leaf_list[LEAVES ? LIN_MAX_LEAVES : 1];
+  __shared__ alignas(16) unsigned char s_cam_raw[sizeof(CameraView<R>)];
+  // per wave: the ray queue (component-major: d.xyz, time, o.xyz of entry e at [c][e]), the entries' pixels, and the
+  // two open units' pixel sums ([parity][channel][pixel])
+  __shared__ R s_q[BLOCK / 64][7][64];
+  __shared__ uint32_t s_qpix[BLOCK / 64][64];
+  __shared__ R s_sum[BLOCK / 64][2][3][64];
+  SceneView<R> sc = sc_in;
+  {
+    if (threadIdx.x == 0) *reinterpret_cast<CameraView<R>*>(s_cam_raw) = cam_in;
+    const uint32_t n_l = sc.n_lights < LDS_MAX_LIGHTS ? sc.n_lights : LDS_MAX_LIGHTS;
+    constexpr uint32_t LW = sizeof(Light<R>) / 4;
+    for (uint32_t i = threadIdx.x; i < n_l * LW; i += BLOCK)
+      reinterpret_cast<uint32_t*>(s_lights)[i] = reinterpret_cast<const uint32_t*>(sc.lights)[i];
+    if constexpr (LINEAR)
+      for (uint32_t i = threadIdx.x; i < sc.n_linear * LIN_DWORDS; i += BLOCK) s_lin[i] = __uint_as_float(sc.linear_rec[i]);
+    if constexpr (LEAVES) {
+      auto stage = [&](void* dst, const void* src, uint32_t bytes) {
+        for (uint32_t i = threadIdx.x; i < bytes / 4u; i += BLOCK)
+          reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+      };
+      stage(s_spheres, sc_in.spheres, sc_in.stage_spheres * (uint32_t)sizeof(Real4<R>));
+      stage(s_cubes, sc_in.cubes, sc_in.stage_cubes * (uint32_t)sizeof(Cube<R>));
+      stage(s_complexes, sc_in.complexes, sc_in.stage_complexes * (uint32_t)sizeof(Complex));
+      stage(s_ops, sc_in.ops, sc_in.stage_ops * (uint32_t)sizeof(Op<R>));
+      stage(s_op_tag, sc_in.op_tag, sc_in.stage_ops * 4u);
+      stage(s_leaf_list, sc_in.leaf_list, sc_in.n_leaf_list * 4u);
+      sc.spheres = s_spheres;
+      sc.cubes = s_cubes;
+      sc.complexes = s_complexes;
+      sc.ops = s_ops;
+      sc.op_tag = s_op_tag;
+      sc.leaf_list = s_leaf_list;
+    }
+    __syncthreads();
+  }
+  const CameraView<R>& cam = *reinterpret_cast<const CameraView<R>*>(s_cam_raw);
+  const Light<R>* lights = sc.n_lights <= LDS_MAX_LIGHTS ? s_lights : sc.lights;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint64_t lanes_below = (1ull << lane) - 1ull;
+  R* const q = &s_q[wave][0][0];
+  uint32_t* const qpix = s_qpix[wave];
+  R* const sum = &s_sum[wave][0][0][0];
+#pragma unroll
+  for (uint32_t i = 0; i < 6; ++i) sum[i * 64u + lane] = R(0);
+  __builtin_amdgcn_wave_barrier();
+  const Vec3<R> background(sc.background[0], sc.background[1], sc.background[2]);
+  const bool lens = cam_in.lens_radius != R(0);  // wave-uniform (a kernel argument)
+  [[maybe_unused]] float inv_wm1 = 0.0f, inv_hm1 = 0.0f;
+  if constexpr (LINEAR) {  // (as render_persist_kernel: wave-uniform reciprocals of main.rs:161-163 in scalar registers)
+    inv_wm1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rrcp((float)(a.width - 1)))));
+    inv_hm1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rrcp((float)(a.height - 1)))));
+  }
+
+  Cnt<STATS> cnt;
+  cnt.clear();
+  uint32_t nonfinite = 0;
+  // wave-uniform: the unit being handed out (parity cp), its batches, the queue, the unfinished jobs of both open units
+  uint32_t cp = 0, tx0 = 0, ty0 = 0, s0 = 0, ns = 0, batch = 0, q_head = 0, q_count = 0, q_sample = 0;
+  uint32_t remaining[2] = {0, 0}, ox[2] = {0, 0}, oy[2] = {0, 0};
+  bool exhausted = false;
+  // per lane: the path in flight
+  bool alive = false;
+  uint32_t lp = 0;  // pixel (0..63 of its unit's tile) | unit parity << 6 | orphan << 7
+  RayT<R> ray;
+  Vec3<R> thr;
+  Rng rng;
+  rng.init(a.seed, 0, 0);
+
+  // unit parity p is complete (or is closed early): its sums leave LDS
+  auto flush = [&](uint32_t p) {
+    wave_lds_fence();
+    const uint32_t fx = ox[p] + (lane & 7u), fy = oy[p] + (lane >> 3);
+    if (fx < a.width && fy < a.height) {
+      R* out = accum + 3ull * (fy * a.width + fx);
+      atomicAdd(out + 0, sum[(p * 3u + 0u) * 64u + lane]);
+      atomicAdd(out + 1, sum[(p * 3u + 1u) * 64u + lane]);
+      atomicAdd(out + 2, sum[(p * 3u + 2u) * 64u + lane]);
+    }
+    sum[(p * 3u + 0u) * 64u + lane] = R(0);
+    sum[(p * 3u + 1u) * 64u + lane] = R(0);
+    sum[(p * 3u + 2u) * 64u + lane] = R(0);
+    wave_lds_fence();
+  };
+
+#ifdef RT_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
+  for (;;) {
+    RT_STAMP(0);
+    // (1) lanes without a path take the next rays of the queue; an empty queue is refilled by the whole wave
+    {
+      bool needy = !alive;
+      for (;;) {
+        const uint64_t m = __ballot(needy);
+        if (m == 0) break;
+        if (q_count == 0) {
+          if (batch == ns) {  // every batch of the unit has been generated: the next unit
+            if (exhausted) break;
+            if (remaining[cp ^ 1u] != 0) {  // (paths that outlast a whole unit: close it, they finish as orphans)
+              if (alive && ((lp >> 6) & 1u) == (cp ^ 1u)) lp |= 128u;
+              flush(cp ^ 1u);
+              remaining[cp ^ 1u] = 0;
+            }
+            uint32_t u = 0;
+            if (lane == 0) u = atomicAdd(&stats->unit_counter, 1u);
+            u = __builtin_amdgcn_readfirstlane(u);
+            if (u >= a.total_units) {
+              exhausted = true;
+              break;
+            }
+            cp ^= 1u;
+            const uint32_t chunk = u / a.wave_tiles, tile = u - chunk * a.wave_tiles, trow = tile / a.wave_tiles_x;
+            tx0 = (tile - trow * a.wave_tiles_x) * 8u;
+            ty0 = trow * 8u;
+            const uint32_t sb = chunk * a.unit_samples;
+            ns = a.n_samples - sb < a.unit_samples ? a.n_samples - sb : a.unit_samples;
+            s0 = a.sample_begin + sb;
+            batch = 0;
+            ox[cp] = tx0;
+            oy[cp] = ty0;
+            const uint32_t in_image =
+                (uint32_t)__popcll(__ballot(tx0 + (lane & 7u) < a.width && ty0 + (lane >> 3) < a.height));
+            remaining[cp] = in_image * ns;  // (a tile that straddles the image edge has fewer than 64 pixels)
+          }
+          // one batch: sample s0 + batch of every pixel of the tile, generated by all lanes together (main.rs:160-164)
+          const uint32_t gx = tx0 + (lane & 7u), gy = ty0 + (lane >> 3);
+          const bool inside = gx < a.width && gy < a.height;
+          const uint64_t vm = __ballot(inside);
+          wave_lds_fence();  // (the entries popped so far have been read)
+          if (inside) {
+            Rng cr;
+            cr.init(a.seed, gy * a.width + gx, s0 + batch);
+            cr.begin(0);
+            const R ju = cr.next<R>();
+            const R jv = cr.next<R>();
+            R u, v;
+            if constexpr (LINEAR) {
+              u = ((R)gx + ju) * inv_wm1;
+              v = ((R)(a.height - gy - 1) + jv) * inv_hm1;
+            } else {  // (the quotient itself, which is what the oracle computes)
+              u = rdiv((R)gx + ju, (R)(a.width - 1));
+              v = rdiv((R)(a.height - gy - 1) + jv, (R)(a.height - 1));
+            }
+            const RayT<R> cray = camera_ray(cam, u, v, cr);
+            const uint32_t e = (uint32_t)__popcll(vm & lanes_below);
+            q[0 * 64u + e] = cray.d.x;
+            q[1 * 64u + e] = cray.d.y;
+            q[2 * 64u + e] = cray.d.z;
+            q[3 * 64u + e] = cray.time;
+            if (lens) {
+              q[4 * 64u + e] = cray.o.x;
+              q[5 * 64u + e] = cray.o.y;
+              q[6 * 64u + e] = cray.o.z;
+            }
+            qpix[e] = lane;
+          }
+          wave_lds_fence();
+          q_head = 0;
+          q_count = (uint32_t)__popcll(vm);
+          q_sample = s0 + batch;
+          ++batch;
+          if (q_count == 0) continue;
+        }
+        const uint32_t rank = (uint32_t)__popcll(m & lanes_below);
+        if (needy && rank < q_count) {
+          const uint32_t e = q_head + rank;
+          ray.d = Vec3<R>(q[0 * 64u + e], q[1 * 64u + e], q[2 * 64u + e]);
+          ray.time = q[3 * 64u + e];
+          if (lens)
+            ray.o = Vec3<R>(q[4 * 64u + e], q[5 * 64u + e], q[6 * 64u + e]);
+          else
+            ray.o = cam.origin;
+          if constexpr (LEAVES) ray.time = R(0);  // leaf-list scenes hold no moving sphere: drawn, never read
+          const uint32_t pl = qpix[e];
+          lp = pl | (cp << 6);
+          rng.pixel = (ty0 + (pl >> 3)) * a.width + tx0 + (pl & 7u);
+          rng.sample = q_sample;
+          rng.set_slot(0);
+          thr = Vec3<R>(1, 1, 1);
+          alive = true;
+          needy = false;
+        }
+        const uint32_t asked = (uint32_t)__popcll(m), taken = asked < q_count ? asked : q_count;
+        q_head += taken;
+        q_count -= taken;
+      }
+    }
+    RT_STAMP(1);  // job hand-over (and camera batches)
+    if (__ballot(alive) == 0) break;  // nothing in flight and nothing left to hand out
+    bool finished = false;
+    if (alive) {  // (every lane, except in the launch's last iterations)
+      // slot b = the b-th ray of the path (also its depth counter); its block is generated after the walk
+      rng.set_slot(rng.slot + 1u);
+      cnt.template inc<ST_RAYS>();
+      RT_STAMP(3);
+      R t;
+      uint32_t best;
+      if constexpr (LINEAR) {
+        if (sc.linear_has_media)  // wave-uniform
+          traverse_linear<STATS, true>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
+        else
+          traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
+      } else {
+        traverse_leaves(sc, ray, R(0.001), rng, t, best, cnt);
+      }
+      RT_STAMP(4);  // walk
+      Vec3<R> L(0, 0, 0);  // set once, at the path's last vertex (see render_persist_kernel)
+      bool cont;
+      if (best == REF_NONE) {  // main.rs:104
+        cnt.template inc<ST_MISSES>();
+        L = madd(L, thr, background);
+        cont = false;
+      } else {
+        cnt.template inc<ST_CLOSEST>();
+        HitRec<R> h;
+        Material<R> mat;
+        if constexpr (LINEAR) {
+          lin_hit_record(sc, s_lin + best * LIN_DWORDS, ray, t, h, mat);
+        } else {
+          make_hit_record(sc, best, ray, t, false, h);
+          mat = sc.materials[h.material];
+        }
+        RT_STAMP(5);  // hit record
+        rng.refill();
+        cont = shade<R, STATS, false>(sc, lights, mat, h, ray, thr, L, rng, cnt);
+      }
+      RT_STAMP(6);  // shade (or miss)
+      if (rng.slot == a.max_depth && cont) {  // the next ray_color call would return 0
+        depth_exhausted(L, thr);
+        cont = false;
+      }
+      if (EARLY_EXIT && cont && thr.x == R(0) && thr.y == R(0) && thr.z == R(0)) cont = false;
+      if (!cont) {
+        const bool fin = rfinite(L.x) && rfinite(L.y) && rfinite(L.z);
+        if (!fin) ++nonfinite;
+        // (f32 drops a non-finite sample; the f64 kernel lets it poison the pixel like the reference does)
+        if (fin || sizeof(R) == 8) {
+          if (!(lp & 128u)) {
+            R* acc = sum + ((lp >> 6) & 1u) * 192u + (lp & 63u);
+            atomicAdd(acc + 0, L.x);
+            atomicAdd(acc + 64, L.y);
+            atomicAdd(acc + 128, L.z);
+          } else {
+            R* out = accum + 3ull * rng.pixel;
+            atomicAdd(out + 0, L.x);
+            atomicAdd(out + 1, L.y);
+            atomicAdd(out + 2, L.z);
+          }
+        }
+        alive = false;
+        finished = !(lp & 128u);  // (an orphan's unit has been closed already)
+      }
+    }
+    {
+      const uint64_t f = __ballot(finished);
+      if (f) {
+        const uint32_t f1 = (uint32_t)__popcll(__ballot(finished && (lp & 64u))), f0 = (uint32_t)__popcll(f) - f1;
+        remaining[0] -= f0;
+        remaining[1] -= f1;
+        if (f0 && remaining[0] == 0) flush(0);
+        if (f1 && remaining[1] == 0) flush(1);
+      }
+    }
+    RT_STAMP(7);
+  }
+#ifdef RT_STAMPS
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&stats->stamp[i], stamp_acc[i]);
+#endif
+  flush_stats(cnt, stats);
+  uint32_t nf = wave_sum(nonfinite);
+  if ((threadIdx.x & 63) == 0 && nf) atomicAdd(&stats->v[ST_NONFINITE], (unsigned long long)nf);
+}
+
 // Small scenes, f32: the leaf-list megakernel with the workgroup's paths SORTED through LDS once per
 // vertex ("a wavefront queue that never leaves the CU").
 //

@@ -48,6 +48,15 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   a.xcd_chunk = shape.xcd_chunk;
   a.tile_band = shape.tile_band;
 #if RT_HAS_LINEAR
+  // render_queue_kernel (jobs not tied to lanes, camera rays a wave at a time) instead of render_persist_kernel
+  static const bool use_queue = getenv("RT_QUEUE") != nullptr && atoi(getenv("RT_QUEUE")) != 0;
+  if (shape.trav == TRAV_LINEAR && shape.unit_samples > 0 && use_queue && max_depth < 65536) {
+    if (stats)
+      RT_LAUNCH((render_queue_kernel<RT_REAL, true, TRAV_LINEAR, RT_EARLY_EXIT>), grid, block, 0, st, sc, cam, a, accum, dstats);
+    else
+      RT_LAUNCH((render_queue_kernel<RT_REAL, false, TRAV_LINEAR, RT_EARLY_EXIT>), grid, block, 0, st, sc, cam, a, accum, dstats);
+    return hipGetLastError();
+  }
   if (shape.trav == TRAV_LINEAR && shape.unit_samples > 0) {  // persistent form: grid = workers, not tiles
     if (stats)
       RT_LAUNCH((render_persist_kernel<RT_REAL, true>), grid, block, 0, st, sc, cam, a, accum, dstats);
@@ -107,6 +116,14 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   if constexpr (F64) {
     // leaf-list scenes (rt_api.hip: make_shape): the leaf list over the scene arrays, persistent form, without the
     // extension code (scenes that use an extension take the reference-order kernel below)
+    static const bool use_queue64 = getenv("RT_QUEUE") == nullptr || atoi(getenv("RT_QUEUE")) != 0;  // the default in f64 (RT_QUEUE=0: render_persist_kernel, A/B)
+    if (shape.trav == TRAV_LEAVES && shape.unit_samples > 0 && !sc.has_noise && use_queue64) {
+      if (stats)
+        RT_LAUNCH((render_queue_kernel<RT_REAL, true, TRAV_LEAVES, RT_EARLY_EXIT>), grid, block, 0, st, sc, cam, a, accum, dstats);
+      else
+        RT_LAUNCH((render_queue_kernel<RT_REAL, false, TRAV_LEAVES, RT_EARLY_EXIT>), grid, block, 0, st, sc, cam, a, accum, dstats);
+      return hipGetLastError();
+    }
     if (shape.trav == TRAV_LEAVES && shape.unit_samples > 0 && !sc.has_noise) {
       if (stats)
         RT_LAUNCH((render_persist_kernel<RT_REAL, true, TRAV_LEAVES, RT_EARLY_EXIT, false>), grid, block, 0, st, sc, cam, a, accum,
