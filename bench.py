@@ -160,7 +160,7 @@ class Workload:
         d = self.hs.desc
         small = "RT_FLAG_FORCE_BVH" in counted_on or d.n_nodes == 0
         if f64:
-            return "render_persist_kernel<double, ..., TRAV_LEAVES>" if small else "render_persist_kernel<double, ..., TRAV_ORDERED>"
+            return "render_queue_kernel<double, ..., TRAV_LEAVES>" if small else "render_persist_kernel<double, ..., TRAV_ORDERED>"
         return "render_persist_kernel<float, ..., TRAV_LINEAR>" if small else "render_units_kernel"
 
 
