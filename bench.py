@@ -160,7 +160,7 @@ class Workload:
         d = self.hs.desc
         small = "RT_FLAG_FORCE_BVH" in counted_on or d.n_nodes == 0
         if f64:
-            return "render_queue_kernel<double, ..., TRAV_LEAVES>" if small else "render_persist_kernel<double, ..., TRAV_ORDERED>"
+            return "render_queue_kernel<double, ..., TRAV_LEAVES>" if small else "render_queue_kernel<double, ..., TRAV_ORDERED>"
         return "render_persist_kernel<float, ..., TRAV_LINEAR>" if small else "render_units_kernel"
 
 
@@ -317,7 +317,7 @@ def other_configs(R, torch, device, skip_big=False):
             s64 = float(w64) * wl.height * spp64
             line["f64"] = {"workload": workload_key(scene, w64, wl.height, spp64, depth, n, True), "ms_per_step": 1e3 * secs,
                            "value": rays / secs / 1e6, "unit": "Mrays/s", "msamples_per_s": s64 / secs / 1e6,
-                           "rays_per_sample": rays / s64, "kernel": "render_persist_kernel<double, ..., TRAV_ORDERED>"}
+                           "rays_per_sample": rays / s64, "kernel": "render_queue_kernel<double, ..., TRAV_ORDERED> (deep trees: render_persist_kernel)"}
             del wl
             torch.cuda.empty_cache()
         lines.append(line)

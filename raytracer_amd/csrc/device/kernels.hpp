@@ -1607,9 +1607,15 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
 template <typename R, bool STATS, int TRAV, bool EARLY_EXIT>
 __global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? RT_QUEUE_F32_MIN_WAVES : RT_QUEUE_F64_MIN_WAVES)
     render_queue_kernel(SceneView<R> sc_in, CameraView<R> cam_in, RenderArgs a, R* __restrict__ accum, DeviceStats* stats) {
-  constexpr bool LINEAR = TRAV == TRAV_LINEAR, LEAVES = TRAV == TRAV_LEAVES;
-  static_assert(LINEAR || LEAVES, "leaf-list forms only");
+  constexpr bool LINEAR = TRAV == TRAV_LINEAR, LEAVES = TRAV == TRAV_LEAVES, ORDERED = TRAV == TRAV_ORDERED;
+  static_assert(LINEAR || LEAVES || ORDERED, "leaf-list forms, or the ordered walk as a state machine");
   static_assert(!LINEAR || sizeof(R) == 4, "the LDS leaf records are f32");
+  // TRAV_ORDERED (f64 on scenes too large for the leaf list): the walk's stack in dynamic LDS, 32-bit references and,
+  // behind them, 16-bit box-entry distances (launch_impl.hpp sizes both); the walk is OrderedWalkR's state machine —
+  // lanes whose walk is over go on to their vertex and take their next ray while the others keep walking
+  extern __shared__ uint32_t lds_stack[];
+  [[maybe_unused]] uint32_t* stack = lds_stack + threadIdx.x;
+  [[maybe_unused]] uint16_t* stack_t = reinterpret_cast<uint16_t*>(lds_stack + (size_t)a.stack_depth * BLOCK) + threadIdx.x;
   __shared__ Light<R> s_lights[LDS_MAX_LIGHTS];
   __shared__ float s_lin[LINEAR ? LIN_MAX_LEAVES * LIN_DWORDS : 1];
   __shared__ Real4<R> s_spheres[LEAVES ? STAGE_MAX_SPHERES : 1];
@@ -1685,6 +1691,14 @@ __global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? RT_QUEUE_F32_MIN_WAVES
   Vec3<R> thr;
   Rng rng;
   rng.init(a.seed, 0, 0);
+  [[maybe_unused]] bool walking = false;
+  [[maybe_unused]] OrderedWalkR<R> walk;
+  walk.cur = REF_NONE;
+  walk.sp = 0;
+  walk.best = REF_NONE;
+  walk.closest = R(0);
+  walk.a = R(0);
+  walk.inv_d = Vec3<R>(0, 0, 0);
 
   // unit parity p is complete (or is closed early): its sums leave LDS
   auto flush = [&](uint32_t p) {
@@ -1809,19 +1823,52 @@ __global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? RT_QUEUE_F32_MIN_WAVES
     RT_STAMP(1);  // job hand-over (and camera batches)
     if (__ballot(alive) == 0) break;  // nothing in flight and nothing left to hand out
     bool finished = false;
-    if (alive) {  // (every lane, except in the launch's last iterations)
+    [[maybe_unused]] bool at_vertex = alive;
+    if constexpr (ORDERED) {
+      if (alive && !walking) {  // a fresh ray (camera or scattered)
+        rng.set_slot(rng.slot + 1u);
+        cnt.template inc<ST_RAYS>();
+        walking = walk.start(sc, ray);
+      }
+      RT_STAMP(3);
+      const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+      const uint32_t refill_q = (n_alive * a.refill_eighths) >> 3;
+      const uint32_t refill_at = refill_q > 0 ? refill_q : 1u;
+      for (;;) {
+        const uint32_t n_walking = (uint32_t)__popcll(__ballot(walking));
+        if (n_walking == 0 || n_walking + refill_at <= n_alive) break;
+        const uint32_t leaves_at = (n_walking >> a.leaf_shift) > 0 ? (n_walking >> a.leaf_shift) : 1u;
+        for (;;) {  // node steps together ...
+          const bool at_node = walking && !(walk.cur & REF_LEAF);
+          const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node));
+          const uint32_t n_walk_now = (uint32_t)__popcll(__ballot(walking));
+          if (n_node == 0 || n_walk_now - n_node >= leaves_at || n_walk_now + refill_at <= n_alive) break;
+          if (at_node) walking = walk.node_step(sc, ray, R(0.001), stack, stack_t, (uint32_t)BLOCK, cnt);
+        }
+        // ... then the leaf tests together
+        if (walking && (walk.cur & REF_LEAF))
+          walking = walk.leaf_step(sc, ray, R(0.001), rng, stack, stack_t, (uint32_t)BLOCK, cnt);
+      }
+      at_vertex = alive && !walking;
+    }
+    if (at_vertex) {  // (leaf-list forms: every lane, except in the launch's last iterations)
+      R t;
+      uint32_t best;
+      if constexpr (ORDERED) {
+        t = walk.closest;
+        best = walk.best;
+      } else {
       // slot b = the b-th ray of the path (also its depth counter); its block is generated after the walk
       rng.set_slot(rng.slot + 1u);
       cnt.template inc<ST_RAYS>();
       RT_STAMP(3);
-      R t;
-      uint32_t best;
+      }
       if constexpr (LINEAR) {
         if (sc.linear_has_media)  // wave-uniform
           traverse_linear<STATS, true>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
         else
           traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
-      } else {
+      } else if constexpr (LEAVES) {
         traverse_leaves(sc, ray, R(0.001), rng, t, best, cnt);
       }
       RT_STAMP(4);  // walk

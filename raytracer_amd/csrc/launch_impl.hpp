@@ -135,6 +135,17 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
     }
     if (shape.trav == TRAV_ORDERED && shape.unit_samples > 0 && !sc.has_noise) {  // big scenes: the ordered walk in f64
       const size_t lds2 = lds + lds / 2;  // 32-bit refs + 16-bit entry distances
+      // jobs shared by the wave's lanes, camera rays a wave at a time (RT_QUEUE=0: lane = pixel, A/B) — where the
+      // queue's 28 KB of LDS next to the stacks still leave three workgroups per CU (measured in f64: random_scene
+      // 7.6 -> 5.1 ms, final_scene 53 -> 31 ms; 10^6 spheres, 40 KB of stacks: 8.3 -> 11.4 ms, so deep trees keep the
+      // lane = pixel form)
+      if (use_queue64 && lds2 + (28u << 10) <= (160u << 10) / 3u) {
+        if (stats)
+          RT_LAUNCH((render_queue_kernel<RT_REAL, true, TRAV_ORDERED, RT_EARLY_EXIT>), grid, block, lds2, st, sc, cam, a, accum, dstats);
+        else
+          RT_LAUNCH((render_queue_kernel<RT_REAL, false, TRAV_ORDERED, RT_EARLY_EXIT>), grid, block, lds2, st, sc, cam, a, accum, dstats);
+        return hipGetLastError();
+      }
       if (stats)
         RT_LAUNCH((render_persist_kernel<RT_REAL, true, TRAV_ORDERED, RT_EARLY_EXIT, false>), grid, block, lds2, st, sc, cam, a,
                   accum, dstats);
