@@ -10,6 +10,8 @@
 // apart in sample index but stay busy (the recursion of ray_color becomes
 // throughput/radiance registers).  Per-lane BVH stack lives in LDS, column-major by lane.
 #pragma once
+#include <type_traits>
+
 #include "audit.hpp"
 
 namespace rt {
@@ -1605,7 +1607,7 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
 #define RT_QUEUE_F64_MIN_WAVES 4
 #endif
 template <typename R, bool STATS, int TRAV, bool EARLY_EXIT>
-__global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? RT_QUEUE_F32_MIN_WAVES : RT_QUEUE_F64_MIN_WAVES)
+__global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? (TRAV == TRAV_ORDERED ? RT_REFILL_MIN_WAVES : RT_QUEUE_F32_MIN_WAVES) : RT_QUEUE_F64_MIN_WAVES)
     render_queue_kernel(SceneView<R> sc_in, CameraView<R> cam_in, RenderArgs a, R* __restrict__ accum, DeviceStats* stats) {
   constexpr bool LINEAR = TRAV == TRAV_LINEAR, LEAVES = TRAV == TRAV_LEAVES, ORDERED = TRAV == TRAV_ORDERED;
   static_assert(LINEAR || LEAVES || ORDERED, "leaf-list forms, or the ordered walk as a state machine");
@@ -1692,7 +1694,7 @@ __global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? RT_QUEUE_F32_MIN_WAVES
   Rng rng;
   rng.init(a.seed, 0, 0);
   [[maybe_unused]] bool walking = false;
-  [[maybe_unused]] OrderedWalkR<R> walk;
+  [[maybe_unused]] std::conditional_t<sizeof(R) == 4, OrderedWalk, OrderedWalkR<R>> walk;  // (f32: the select-only node step)
   walk.cur = REF_NONE;
   walk.sp = 0;
   walk.best = REF_NONE;
@@ -1844,6 +1846,11 @@ __global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? RT_QUEUE_F32_MIN_WAVES
           const uint32_t n_walk_now = (uint32_t)__popcll(__ballot(walking));
           if (n_node == 0 || n_walk_now - n_node >= leaves_at || n_walk_now + refill_at <= n_alive) break;
           if (at_node) walking = walk.node_step(sc, ray, R(0.001), stack, stack_t, (uint32_t)BLOCK, cnt);
+          if constexpr (sizeof(R) == 4) {  // (a burst of node steps per round of ballots: see render_units_kernel)
+#pragma unroll
+            for (int nb = 1; nb < RT_NODE_BURST; ++nb)
+              if (walking && !(walk.cur & REF_LEAF)) walking = walk.node_step(sc, ray, R(0.001), stack, stack_t, (uint32_t)BLOCK, cnt);
+          }
         }
         // ... then the leaf tests together
         if (walking && (walk.cur & REF_LEAF))

@@ -85,6 +85,16 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
   if (shape.trav == TRAV_ORDERED) {
     const size_t lds2 = lds + lds / 2;  // 32-bit refs + 16-bit entry distances
     static const bool no_refill = getenv("RT_ORDERED_NO_REFILL") != nullptr;
+    if (!no_refill && shape.unit_samples > 0 && use_queue) {  // experiment: the queue kernel around the f32 ordered walk
+      a.wave_tiles_x = (width + 7) / 8;  // (its units are 8x8 tiles in row-major order)
+      a.wave_tiles = a.wave_tiles_x * ((height + 7) / 8);
+      a.total_units = a.wave_tiles * ((n_samples + a.unit_samples - 1) / a.unit_samples);
+      if (stats)
+        RT_LAUNCH((render_queue_kernel<RT_REAL, true, TRAV_ORDERED, RT_EARLY_EXIT>), grid, block, lds2, st, sc, cam, a, accum, dstats);
+      else
+        RT_LAUNCH((render_queue_kernel<RT_REAL, false, TRAV_ORDERED, RT_EARLY_EXIT>), grid, block, lds2, st, sc, cam, a, accum, dstats);
+      return hipGetLastError();
+    }
     if (!no_refill && shape.unit_samples > 0) {  // persistent waves, work units from a counter: grid = workers
       const size_t lds3 = lds2 + (shape.direct_accum ? 0 : (BLOCK / 64) * UNITS_LDS_FLOATS * sizeof(float));
       if (stats)
