@@ -71,7 +71,7 @@ if have:
                 body.append(line)
             elif "kernel_ms" in line and not any("kernel_ms" in b for b in body):
                 body.append(line.split(":", 1)[-1])
-        kern = "render_persist_kernel<double, ..., TRAV_LEAVES>" if k == "f64" else "render_units_kernel"
+        kern = "render_queue_kernel<double, ..., TRAV_LEAVES>" if k == "f64" else "render_units_kernel"
         L += [f"### {title} — `{kern}`", "", "```"] + body + ["```", ""]
 
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
