@@ -218,7 +218,7 @@ template <typename R> RT_DEV R second_probe_start(R t1) {
 // (hittable.rs:319-386).  All wrappers are rigid, so t is the same in every frame.
 template <typename R, bool STATS>
 RT_DEV bool complex_t(const SceneView<R>& sc, uint32_t idx, const RayT<R>& r, R t_min, R t_max, Rng& rng,
-                      R& t_out, Cnt<STATS>& cnt, RayT<R>* mapped = nullptr) {
+                      R& t_out, Cnt<STATS>& cnt) {
   Complex cx = sc.complexes[idx];
   RayT<R> lr = r;
   Vec3<R> dm = r.d;  // direction in the medium's frame
@@ -251,7 +251,6 @@ RT_DEV bool complex_t(const SceneView<R>& sc, uint32_t idx, const RayT<R>& r, R 
   }
   Vec3<R> inv_d = inverse3(lr.d);
   R a = sqrlen(lr.d);
-  if (mapped) *mapped = lr;  // the ray in the body's frame (what the hit record of a complex without a medium starts from)
   if (cx.medium_pos == REF_NONE) return prim_t(sc, cx.body, lr, inv_d, a, t_min, t_max, t_out, cnt);
 
   // hittable.rs:319-349
@@ -840,12 +839,9 @@ RT_DEV void traverse_linear(const float* lin, uint32_t n_linear, LinMasks masks,
 // work: no node tests, and the leaves a node box would have pruned are tested (and rejected).  The loop counter and
 // the leaf reference are wave-uniform: no traversal divergence, no stack.  This is what the f64 kernel walks on scenes
 // the f32 kernels take the leaf list for (same eligibility: verified-conservative boxes, <= LIN_MAX_LEAVES leaves).
-// `stash` (optional; this lane's column of an LDS array, entry i at stash[i * stash_stride]): whenever a complex leaf
-// becomes the winner, the ray in its body's frame — which complex_t has just computed through the wrapper chain — is
-// kept there, so that the hit record of a winning complex (make_hit_record) need not walk the chain a second time.
 template <typename R, bool STATS>
 RT_DEV void traverse_leaves(const SceneView<R>& sc, const RayT<R>& r, R t_min, Rng& rng, R& closest, uint32_t& best,
-                            Cnt<STATS>& cnt, R* stash = nullptr, uint32_t stash_stride = 0) {
+                            Cnt<STATS>& cnt) {
   closest = Consts<R>::inf;
   best = REF_NONE;
   const Vec3<R> inv_d = inverse3(r.d);
@@ -854,18 +850,9 @@ RT_DEV void traverse_leaves(const SceneView<R>& sc, const RayT<R>& r, R t_min, R
     const uint32_t ref = __builtin_amdgcn_readfirstlane(sc.leaf_list[k]);  // wave-uniform
     R t;
     bool h;
-    if (ref_kind(ref) == LEAF_COMPLEX) {
-      RayT<R> lr;
-      h = complex_t(sc, ref_index(ref), r, t_min, closest, rng, t, cnt, stash ? &lr : nullptr);
-      if (stash && h && (best == REF_NONE || t < closest)) {
-        stash[0] = lr.o.x;
-        stash[stash_stride] = lr.o.y;
-        stash[2 * stash_stride] = lr.o.z;
-        stash[3 * stash_stride] = lr.d.x;
-        stash[4 * stash_stride] = lr.d.y;
-        stash[5 * stash_stride] = lr.d.z;
-      }
-    } else
+    if (ref_kind(ref) == LEAF_COMPLEX)
+      h = complex_t(sc, ref_index(ref), r, t_min, closest, rng, t, cnt);
+    else
       h = prim_t(sc, ref, r, inv_d, a, t_min, closest, t, cnt);
     if (h && (best == REF_NONE || t < closest)) {  // as traverse(): hittable.rs:405-411
       closest = t;
@@ -950,11 +937,9 @@ RT_DEV void prim_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, 
   }
 }
 
-// `stash` (f64 leaf-list walk only): the winner's mapped ray as traverse_leaves left it (valid when the winner is a
-// complex without a medium: same values as the chain below computes, bit for bit — it is the same code's result)
 template <typename R>
 RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>& r, R t, bool force_uv,
-                            HitRec<R>& h, const R* stash = nullptr, uint32_t stash_stride = 0) {
+                            HitRec<R>& h) {
   if constexpr (sizeof(R) == 4) {
     // f32: one shared copy of the primitive code for bare and wrapped primitives (lanes of a
     // wave that hit a wall and lanes that hit a rotated box run the same cube code together).
@@ -1000,10 +985,6 @@ RT_DEV void make_hit_record(const SceneView<R>& sc, uint32_t ref, const RayT<R>&
     cx = sc.complexes[ref_index(ref)];
     n_outer = cx.medium_pos == REF_NONE ? cx.op_count : cx.medium_pos;
     body = cx.body;
-    if (stash && cx.medium_pos == REF_NONE) {
-      lr.o = Vec3<R>(stash[0], stash[stash_stride], stash[2 * stash_stride]);
-      lr.d = Vec3<R>(stash[3 * stash_stride], stash[4 * stash_stride], stash[5 * stash_stride]);
-    } else
     for (uint32_t k = 0; k < n_outer; ++k) {
       uint32_t tag = sc.op_tag[cx.op_first + k];
       Op<R> op = sc.ops[cx.op_first + k];

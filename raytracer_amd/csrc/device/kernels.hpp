@@ -1279,14 +1279,6 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
   __shared__ uint32_t s_leaf_list[LEAVES ? LIN_MAX_LEAVES : 1];
   // ... and the camera (24 doubles that are read once per sample): in LDS they cost no scalar registers between samples
   __shared__ alignas(16) unsigned char s_cam_raw[LEAVES ? sizeof(CameraView<R>) : 16];
-  // ... and, per lane, the winning complex leaf's mapped ray (6 reals, column-major by lane): computed by the walk, read
-  // by the hit record (see traverse_leaves)
-#ifdef RT_LEAF_STASH
-  __shared__ R s_stash_all[LEAVES ? 6 * BLOCK : 1];
-  [[maybe_unused]] R* stash = LEAVES ? s_stash_all + threadIdx.x : nullptr;
-#else
-  [[maybe_unused]] R* stash = nullptr;
-#endif
   // f64 leaf-list form: the lane's running pixel sum lives in LDS (3 reals, column-major by lane), not in 6 vector
   // registers the walk would spill; it is touched once per finished sample.  (Not the stack-walking forms: their LDS
   // decides how many workgroups a CU holds — 10^6 spheres in f64: 116.5 -> 130.9 ms with these 6 KB.)
@@ -1525,7 +1517,7 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
       else
         traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
     } else if constexpr (LEAVES) {
-      traverse_leaves(sc, ray, R(0.001), rng, t, best, cnt, stash, (uint32_t)BLOCK);
+      traverse_leaves(sc, ray, R(0.001), rng, t, best, cnt);
     } else {
       traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
     }
@@ -1546,10 +1538,7 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
       if constexpr (LINEAR) {
         lin_hit_record(sc, s_lin + best * LIN_DWORDS, ray, t, h, mat);
       } else {
-        if constexpr (LEAVES)
-          make_hit_record(sc, best, ray, t, false, h, stash, (uint32_t)BLOCK);
-        else
-          make_hit_record(sc, best, ray, t, false, h);
+        make_hit_record(sc, best, ray, t, false, h);
         mat = sc.materials[h.material];
       }
       RT_STAMP(5);  // hit record

