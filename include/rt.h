@@ -327,6 +327,11 @@ typedef struct rt_multi rt_multi;
 int rt_multi_create(int n_dev, const int* devices, const rt_scene_desc* desc, rt_multi** out);
 int rt_multi_render(rt_multi* multi, const rt_camera* cam, const rt_params* params, float* accum_rgb,
                     rt_stats* per_dev);
+/* The same in the reference's own arithmetic (f64, alias.rs:4-7): every shard runs the kernels of rt_render_f64_device,
+ * the shards are summed in f64 in shard order; accum_rgb is [h][w][3] f64 SUM on the host.  The union of the shards'
+ * paths is the single-device render's, path for path; only the order of a pixel's sum differs (1e-16 relative). */
+int rt_multi_render_f64(rt_multi* multi, const rt_camera* cam, const rt_params* params, double* accum_rgb,
+                        rt_stats* per_dev);
 void rt_multi_destroy(rt_multi* multi);
 /* The sample range of shard g of n_dev: first = g*spp/n_dev, count = (g+1)*spp/n_dev - first (integer
  * division): contiguous, disjoint, covering [0, spp) for any n_dev, sizes within one of each other.

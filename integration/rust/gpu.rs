@@ -154,6 +154,9 @@ extern "C" {
     pub fn rt_multi_create(n_dev: c_int, devices: *const c_int, desc: *const RtSceneDesc, out: *mut *mut RtMulti) -> c_int;
     pub fn rt_multi_render(multi: *mut RtMulti, cam: *const RtCamera, p: *const RtParams, accum_rgb: *mut f32,
                            per_dev: *mut RtStats) -> c_int;
+    // ... in the reference's own arithmetic (alias.rs:4-7): the f64 kernels on every shard, f64 sums
+    pub fn rt_multi_render_f64(multi: *mut RtMulti, cam: *const RtCamera, p: *const RtParams, accum_rgb: *mut f64,
+                               per_dev: *mut RtStats) -> c_int;
     pub fn rt_multi_destroy(multi: *mut RtMulti);
     pub fn rt_multi_shard(spp: u64, g: u32, n_dev: u32, first: *mut u64, count: *mut u64);
     pub fn rt_primary_hits(scene: *mut RtScene, cam: *const RtCamera, width: u32, height: u32, seed: u64, time: f64,

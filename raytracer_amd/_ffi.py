@@ -99,7 +99,7 @@ class RthRenderOpts(C.Structure):
 # every symbol include/rt.h and include/rt_host.h declare (tests check the export lists against the headers)
 RT_SYMBOLS = [
     "rt_scene_create", "rt_scene_destroy", "rt_primary_hits", "rt_primary_hits_f64", "rt_primary_hits_fast", "rt_primary_redecided", "rt_render",
-    "rt_render_f64", "rt_render_device", "rt_render_f64_device", "rt_render_device_noalloc", "rt_render_multi", "rt_multi_create", "rt_multi_render", "rt_multi_destroy", "rt_multi_shard", "rt_debug_build_tree", "rt_tonemap", "rt_tonemap_device", "rt_tonemap_f64", "rt_tonemap_f64_device", "rt_kat_sphere_uv", "rt_kat_rotate",
+    "rt_render_f64", "rt_render_device", "rt_render_f64_device", "rt_render_device_noalloc", "rt_render_multi", "rt_multi_create", "rt_multi_render", "rt_multi_render_f64", "rt_multi_destroy", "rt_multi_shard", "rt_debug_build_tree", "rt_tonemap", "rt_tonemap_device", "rt_tonemap_f64", "rt_tonemap_f64_device", "rt_kat_sphere_uv", "rt_kat_rotate",
     "rt_kat_philox", "rt_kat_libm", "rt_device_count", "rt_abi_version", "rt_last_error",
 ]
 RTH_SYMBOLS = [
@@ -145,6 +145,7 @@ hip.rt_render_multi.argtypes = [C.c_int, C.POINTER(C.c_int), _p, C.POINTER(RtCam
                                 C.POINTER(RtStats)]
 hip.rt_multi_create.argtypes = [C.c_int, C.POINTER(C.c_int), _p, C.POINTER(_p)]
 hip.rt_multi_render.argtypes = [_p, C.POINTER(RtCamera), C.POINTER(RtParams), _p, C.POINTER(RtStats)]
+hip.rt_multi_render_f64.argtypes = [_p, C.POINTER(RtCamera), C.POINTER(RtParams), _p, C.POINTER(RtStats)]
 hip.rt_multi_destroy.argtypes = [_p]
 hip.rt_multi_destroy.restype = None
 hip.rt_multi_shard.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, _u64p, _u64p]

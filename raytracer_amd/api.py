@@ -238,13 +238,15 @@ class MultiScene:
             pass
 
     def render(self, width, height, spp, max_depth, seed=1, sample_offset=0, spp_per_launch=0, stats=False,
-               per_device=True, camera=None):
-        """rt_multi_render.  Returns (accum SUM [h][w][3] float32, [per-device stats dict] or None)."""
+               per_device=True, camera=None, f64=False):
+        """rt_multi_render (f64=True: rt_multi_render_f64, the reference's arithmetic).
+        Returns (accum SUM [h][w][3] float32 or float64, [per-device stats dict] or None)."""
         p = _multi_params(width, height, spp, max_depth, seed, sample_offset, spp_per_launch, stats)
         st = (F.RtStats * len(self.devices))() if per_device else None
-        accum = np.zeros((height, width, 3), dtype=np.float32)
+        accum = np.zeros((height, width, 3), dtype=np.float64 if f64 else np.float32)
         cam = camera if camera is not None else self.host.camera
-        F.check_hip(F.hip.rt_multi_render(self._h, C.byref(cam), C.byref(p), _ptr(accum), st))
+        fn = F.hip.rt_multi_render_f64 if f64 else F.hip.rt_multi_render
+        F.check_hip(fn(self._h, C.byref(cam), C.byref(p), _ptr(accum), st))
         return accum, ([s.as_dict() for s in st] if per_device else None)
 
 

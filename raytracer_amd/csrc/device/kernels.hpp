@@ -2449,13 +2449,14 @@ __global__ void zero_kernel(uint32_t* __restrict__ dst, uint64_t n) {
   for (; i < n; i += stride) dst[i] = 0u;
 }
 
-// dst[i] = ((dst[i] + src[i]) + src[n + i]) + ... over n_src images of n floats each, in that order (the accumulators
-// of the other devices' sample shards, rt_multi_render)
-__global__ void accum_add_kernel(float* __restrict__ dst, const float* __restrict__ src, uint64_t n, uint32_t n_src) {
+// dst[i] = ((dst[i] + src[i]) + src[n + i]) + ... over n_src images of n values each, in that order (the accumulators
+// of the other devices' sample shards, rt_multi_render / rt_multi_render_f64)
+template <typename T>
+__global__ void accum_add_kernel(T* __restrict__ dst, const T* __restrict__ src, uint64_t n, uint32_t n_src) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    float a = dst[i];
+    T a = dst[i];
     for (uint32_t k = 0; k < n_src; ++k) a += src[(uint64_t)k * n + i];
     dst[i] = a;
   }

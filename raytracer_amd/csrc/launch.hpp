@@ -62,6 +62,7 @@ hipError_t launch_tonemap(const float* accum, uint64_t n, float inv_spp, uint8_t
 hipError_t launch_tonemap_f64(const double* accum, uint64_t n, double spp, uint8_t* out, hipStream_t st);
 hipError_t launch_zero(void* dst, size_t bytes, hipStream_t st);
 hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, uint32_t n_src, hipStream_t st);
+hipError_t launch_accum_add_f64(double* dst, const double* src, uint64_t n, uint32_t n_src, hipStream_t st);
 hipError_t launch_kat_libm(uint32_t n, uint32_t op, const double* a, const double* b, double* out, hipStream_t st);
 hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, int path_stream, uint32_t* out,
                              hipStream_t st);

@@ -326,7 +326,14 @@ hipError_t launch_accum_add(float* dst, const float* src, uint64_t n, uint32_t n
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks == 0) blocks = 1;
-  RT_LAUNCH(accum_add_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, dst, src, n, n_src);
+  RT_LAUNCH(accum_add_kernel<float>, dim3((uint32_t)blocks), dim3(256), 0, st, dst, src, n, n_src);
+  return hipGetLastError();
+}
+hipError_t launch_accum_add_f64(double* dst, const double* src, uint64_t n, uint32_t n_src, hipStream_t st) {
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) blocks = 1;
+  RT_LAUNCH(accum_add_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, st, dst, src, n, n_src);
   return hipGetLastError();
 }
 hipError_t launch_kat_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, int path_stream, uint32_t* out,

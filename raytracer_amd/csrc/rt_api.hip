@@ -1608,10 +1608,10 @@ int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, const rt_params*
 struct rt_multi {
   std::vector<int> devices;
   std::vector<rt_scene*> scenes;
-  std::vector<float*> accum;  // per entry, on its device: `capacity` floats
+  std::vector<void*> accum;  // per entry, on its device: `capacity` bytes (f32 or f64 sums, whichever the render asks for)
   std::vector<hipStream_t> streams;
   std::vector<hipEvent_t> done;
-  float* staging = nullptr;  // on devices[0]: (G-1) x capacity floats
+  void* staging = nullptr;  // on devices[0]: (G-1) x capacity bytes
   size_t capacity = 0;
 };
 
@@ -1688,34 +1688,36 @@ int rt_multi_create(int n_dev, const int* devices, const rt_scene_desc* desc, rt
   return RT_OK;
 }
 
-static int multi_reserve(rt_multi* m, size_t n_floats) {
-  if (n_floats <= m->capacity) return RT_OK;
+static int multi_reserve(rt_multi* m, size_t want_bytes) {
+  if (want_bytes <= m->capacity) return RT_OK;
   const size_t G = m->devices.size();
-  const size_t bytes = std::max<size_t>(n_floats * sizeof(float), 16);
+  const size_t bytes = std::max<size_t>(want_bytes, 16);
   for (size_t g = 0; g < G; ++g) {
     HIP_TRY(hipSetDevice(m->devices[g]));
     HIP_TRY(hipStreamSynchronize(m->streams[g]));
     if (m->accum[g]) (void)hipFree(m->accum[g]);
     m->accum[g] = nullptr;
     m->capacity = 0;
-    HIP_TRY(hipMalloc((void**)&m->accum[g], bytes));
+    HIP_TRY(hipMalloc(&m->accum[g], bytes));
     if (g == 0) {
       if (m->staging) (void)hipFree(m->staging);
       m->staging = nullptr;
-      if (G > 1) HIP_TRY(hipMalloc((void**)&m->staging, bytes * (G - 1)));
+      if (G > 1) HIP_TRY(hipMalloc(&m->staging, bytes * (G - 1)));
     }
   }
-  m->capacity = n_floats;
+  m->capacity = bytes;
   return RT_OK;
 }
 
-int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, float* accum, rt_stats* per_dev) {
-  if (!m || !p || !accum) return fail(RT_ERR_BAD_ARG, "rt_multi_render: null argument");
+}  // extern "C"
+template <typename R>
+static int multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, R* accum, rt_stats* per_dev, const char* who) {
+  if (!m || !p || !accum) return fail(RT_ERR_BAD_ARG, "%s: null argument", who);
   if (int rc = check_camera(cam)) return rc;
-  if (int rc = check_params(p, "rt_multi_render")) return rc;  // before any accumulator is sized from them
+  if (int rc = check_params(p, who)) return rc;  // before any accumulator is sized from them
   const size_t G = m->devices.size();
   const size_t n_floats = (size_t)p->width * p->height * 3;
-  if (int rc = multi_reserve(m, n_floats)) return rc;
+  if (int rc = multi_reserve(m, n_floats * sizeof(R))) return rc;
   std::vector<int> rcs(G, RT_OK);
   std::vector<std::string> errs(G);
   auto work = [&](size_t g) {
@@ -1729,14 +1731,14 @@ int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, float
     q.spp = (uint32_t)count;
     q.sample_offset = p->sample_offset + first;
     // stats == NULL keeps the whole call asynchronous; with per_dev the shard's own thread waits for its counters
-    if (int rc = render_on_device<float>(m->scenes[g], cam, &q, m->accum[g], 0, m->streams[g], per_dev ? &per_dev[g] : nullptr))
+    if (int rc = render_on_device<R>(m->scenes[g], cam, &q, static_cast<R*>(m->accum[g]), 0, m->streams[g], per_dev ? &per_dev[g] : nullptr))
       return bail(rc);
     hipError_t e = hipSuccess;
     if (g > 0)
-      e = hipMemcpyPeerAsync(m->staging + (g - 1) * n_floats, m->devices[0], m->accum[g], m->devices[g],
-                             n_floats * sizeof(float), m->streams[g]);
+      e = hipMemcpyPeerAsync(static_cast<R*>(m->staging) + (g - 1) * n_floats, m->devices[0], m->accum[g], m->devices[g],
+                             n_floats * sizeof(R), m->streams[g]);
     if (e == hipSuccess && g > 0) e = hipEventRecord(m->done[g], m->streams[g]);
-    if (e != hipSuccess) bail(fail(RT_ERR_HIP, "rt_multi_render: shard %zu copy: %s", g, hipGetErrorString(e)));
+    if (e != hipSuccess) bail(fail(RT_ERR_HIP, "%s: shard %zu copy: %s", who, g, hipGetErrorString(e)));
   };
   std::vector<std::thread> pool;
   for (size_t g = 1; g < G; ++g) pool.emplace_back(work, g);
@@ -1746,21 +1748,35 @@ int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, float
   for (size_t g = 0; g < G && rc == RT_OK; ++g)
     if (rcs[g] != RT_OK) rc = fail(rcs[g], "device %d: %s", m->devices[g], errs[g].c_str());
   auto hip_ok = [&](hipError_t e, const char* what) {
-    if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_HIP, "rt_multi_render: %s: %s", what, hipGetErrorString(e));
+    if (e != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_HIP, "%s: %s: %s", who, what, hipGetErrorString(e));
     return e == hipSuccess;
   };
   if (rc == RT_OK && hip_ok(hipSetDevice(m->devices[0]), "hipSetDevice")) {
     for (size_t g = 1; g < G && rc == RT_OK; ++g) hip_ok(hipStreamWaitEvent(m->streams[0], m->done[g], 0), "hipStreamWaitEvent");
-    if (rc == RT_OK && G > 1)
-      hip_ok(launch_accum_add(m->accum[0], m->staging, n_floats, (uint32_t)(G - 1), m->streams[0]), "accum_add");
+    if (rc == RT_OK && G > 1) {
+      if constexpr (sizeof(R) == 8)
+        hip_ok(launch_accum_add_f64(static_cast<double*>(m->accum[0]), static_cast<const double*>(m->staging), n_floats,
+                                    (uint32_t)(G - 1), m->streams[0]), "accum_add");
+      else
+        hip_ok(launch_accum_add(static_cast<float*>(m->accum[0]), static_cast<const float*>(m->staging), n_floats,
+                                (uint32_t)(G - 1), m->streams[0]), "accum_add");
+    }
     if (rc == RT_OK)
-      hip_ok(hipMemcpyAsync(accum, m->accum[0], n_floats * sizeof(float), hipMemcpyDeviceToHost, m->streams[0]), "copy back");
+      hip_ok(hipMemcpyAsync(accum, m->accum[0], n_floats * sizeof(R), hipMemcpyDeviceToHost, m->streams[0]), "copy back");
     if (rc == RT_OK) hip_ok(hipStreamSynchronize(m->streams[0]), "hipStreamSynchronize");
   }
   if (rc != RT_OK)  // leave nothing of this call in flight behind an error
     for (size_t g = 0; g < G; ++g)
       if (hipSetDevice(m->devices[g]) == hipSuccess) (void)hipStreamSynchronize(m->streams[g]);
   return rc;
+}
+
+extern "C" {
+int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, float* accum, rt_stats* per_dev) {
+  return multi_render<float>(m, cam, p, accum, per_dev, "rt_multi_render");
+}
+int rt_multi_render_f64(rt_multi* m, const rt_camera* cam, const rt_params* p, double* accum, rt_stats* per_dev) {
+  return multi_render<double>(m, cam, p, accum, per_dev, "rt_multi_render_f64");
 }
 
 int rt_render_multi(int n_dev, const int* devices, const rt_scene_desc* desc, const rt_camera* cam, const rt_params* p,

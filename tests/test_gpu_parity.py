@@ -273,6 +273,29 @@ def test_multi_scene_is_reused_across_renders():
     ms.close()
 
 
+def test_multi_scene_in_the_references_arithmetic():
+    """rt_multi_render_f64: the same sharding with every shard on the f64 kernels, summed in f64 in shard order.  The
+    shards' paths are the single render's path for path (equal work counters), the image equal to the order of the sums;
+    f32 and f64 renders may alternate on one handle (the accumulators are sized in bytes)."""
+    import raytracer_amd as R
+    hs = R.HostScene(6, 1.0)
+    ds = R.DeviceScene(hs, 0)
+    ms = R.MultiScene(hs, [0, 0, 0])
+    for (w, spp) in ((40, 7), (72, 20)):
+        one, s1 = ds.render(w, w, spp, 50, seed=5, sample_offset=2, stats=True, f64=True)
+        multi, sm = ms.render(w, w, spp, 50, seed=5, sample_offset=2, stats=True, f64=True)
+        assert multi.dtype == np.float64
+        for k in ("rays", "closest_hits", "misses", "diffuse_vertices"):
+            assert sum(s[k] for s in sm) == s1[k], k
+        assert np.array_equal(np.isnan(multi), np.isnan(one))
+        ok = np.isfinite(one)
+        np.testing.assert_allclose(multi[ok], one[ok], rtol=1e-12, atol=1e-12)
+        f32, _ = ms.render(w, w, spp, 50, seed=5, sample_offset=2)  # the same handle, the f32 kernels
+        one32, _ = ds.render(w, w, spp, 50, seed=5, sample_offset=2)
+        np.testing.assert_allclose(f32, one32, rtol=2e-5, atol=1e-5)
+    ms.close()
+
+
 @pytest.mark.parametrize("name", list(SCENES))
 def test_f32_tracks_f64_audit_at_equal_seed(name, earthmap):
     """Same seed, same Philox words: the f32 production kernels and the f64 audit kernel follow the same
