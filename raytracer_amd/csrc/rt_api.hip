@@ -222,8 +222,10 @@ hipError_t build_side(const rt_scene_desc& d, const std::vector<Complex>& comple
       const uint32_t n_leaves = (uint32_t)facts.leaf_refs.size();
       std::vector<uint32_t> refs(facts.leaf_refs);
       for (uint32_t& r : refs) r = f32_ref(r);
+      static const char* slack_env = getenv("RT_TREE_SLACK");  // tuning override: levels above a balanced tree's height
+      const uint32_t slack = slack_env ? (uint32_t)std::max(0, atoi(slack_env)) : 6u;
       nodes2 = accel::build_sah(facts.leaf_box.data(), refs.data(), n_leaves,
-                                std::min(MAX_STACK_DEPTH, accel::ceil_log2(n_leaves) + 6u), &s.ordered_height);
+                                std::min(MAX_STACK_DEPTH, accel::ceil_log2(n_leaves) + slack), &s.ordered_height);
       s.ordered_root = 0;
     } else if (facts.conservative && d.n_nodes > 0 && !(d.root & RT_REF_LEAF) && d.root != RT_REF_NONE) {
       nodes2.resize(d.n_nodes);
