@@ -1595,11 +1595,14 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
 #ifndef RT_QUEUE_F64_MIN_WAVES
 #define RT_QUEUE_F64_MIN_WAVES 4
 #endif
-template <typename R, bool STATS, int TRAV, bool EARLY_EXIT>
+template <typename R, bool STATS, int TRAV, bool EARLY_EXIT, bool NOISE = false>
 __global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? (TRAV == TRAV_ORDERED ? RT_REFILL_MIN_WAVES : RT_QUEUE_F32_MIN_WAVES) : RT_QUEUE_F64_MIN_WAVES)
     render_queue_kernel(SceneView<R> sc_in, CameraView<R> cam_in, RenderArgs a, R* __restrict__ accum, DeviceStats* stats) {
   constexpr bool LINEAR = TRAV == TRAV_LINEAR, LEAVES = TRAV == TRAV_LEAVES, ORDERED = TRAV == TRAV_ORDERED;
-  static_assert(LINEAR || LEAVES || ORDERED, "leaf-list forms, or the ordered walk as a state machine");
+  static_assert(LINEAR || LEAVES || ORDERED || TRAV == TRAV_REFERENCE,
+                "leaf-list forms, the ordered walk as a state machine, or the reference-order walk run to completion");
+  // TRAV_REFERENCE (f64: scenes whose boxes clip, extensions — NOISE —, RT_FLAG_FORCE_BVH): the reference's left-first walk,
+  // its 32-bit stack in dynamic LDS
   static_assert(!LINEAR || sizeof(R) == 4, "the LDS leaf records are f32");
   // TRAV_ORDERED (f64 on scenes too large for the leaf list): the walk's stack in dynamic LDS, 32-bit references and,
   // behind them, 16-bit box-entry distances (launch_impl.hpp sizes both); the walk is OrderedWalkR's state machine —
@@ -1866,6 +1869,8 @@ __global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? (TRAV == TRAV_ORDERED 
           traverse_linear<STATS, false>(s_lin, sc.n_linear, lin_masks(sc), ray, R(0.001), rng, t, best, cnt);
       } else if constexpr (LEAVES) {
         traverse_leaves(sc, ray, R(0.001), rng, t, best, cnt);
+      } else if constexpr (!ORDERED) {
+        traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
       }
       RT_STAMP(4);  // walk
       Vec3<R> L(0, 0, 0);  // set once, at the path's last vertex (see render_persist_kernel)
@@ -1886,7 +1891,7 @@ __global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? (TRAV == TRAV_ORDERED 
         }
         RT_STAMP(5);  // hit record
         rng.refill();
-        cont = shade<R, STATS, false>(sc, lights, mat, h, ray, thr, L, rng, cnt);
+        cont = shade<R, STATS, NOISE>(sc, lights, mat, h, ray, thr, L, rng, cnt);
       }
       RT_STAMP(6);  // shade (or miss)
       if (rng.slot == a.max_depth && cont) {  // the next ray_color call would return 0

@@ -164,6 +164,14 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
                   accum, dstats);
       return hipGetLastError();
     }
+    if (shape.trav == TRAV_REFERENCE && shape.unit_samples > 0 && use_queue64 && lds + (28u << 10) <= (160u << 10) / 3u) {
+      // the reference-order walk with the wave's jobs shared (as above; RT_QUEUE=0: lane = pixel)
+      if (stats)
+        RT_LAUNCH((render_queue_kernel<RT_REAL, true, TRAV_REFERENCE, RT_EARLY_EXIT, true>), grid, block, lds, st, sc, cam, a, accum, dstats);
+      else
+        RT_LAUNCH((render_queue_kernel<RT_REAL, false, TRAV_REFERENCE, RT_EARLY_EXIT, true>), grid, block, lds, st, sc, cam, a, accum, dstats);
+      return hipGetLastError();
+    }
     if (shape.trav == TRAV_REFERENCE && shape.unit_samples > 0) {  // persistent form of the audit kernel (rt_api.hip: make_shape)
       if (stats)
         RT_LAUNCH((render_persist_kernel<RT_REAL, true, TRAV_REFERENCE, RT_EARLY_EXIT, true>), grid, block, lds, st, sc, cam, a,
