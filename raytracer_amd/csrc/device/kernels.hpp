@@ -1595,7 +1595,7 @@ __global__ void __launch_bounds__(BLOCK, TRAV == TRAV_LINEAR ? RT_PERSIST_MIN_WA
 #ifndef RT_QUEUE_F64_MIN_WAVES
 #define RT_QUEUE_F64_MIN_WAVES 4
 #endif
-template <typename R, bool STATS, int TRAV, bool EARLY_EXIT, bool NOISE = false>
+template <typename R, bool STATS, int TRAV, bool EARLY_EXIT, bool NOISE = false, int INST = -1>
 __global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? (TRAV == TRAV_ORDERED ? RT_REFILL_MIN_WAVES : RT_QUEUE_F32_MIN_WAVES) : RT_QUEUE_F64_MIN_WAVES)
     render_queue_kernel(SceneView<R> sc_in, CameraView<R> cam_in, RenderArgs a, R* __restrict__ accum, DeviceStats* stats) {
   constexpr bool LINEAR = TRAV == TRAV_LINEAR, LEAVES = TRAV == TRAV_LEAVES, ORDERED = TRAV == TRAV_ORDERED;
@@ -1870,7 +1870,12 @@ __global__ void __launch_bounds__(BLOCK, sizeof(R) == 4 ? (TRAV == TRAV_ORDERED 
       } else if constexpr (LEAVES) {
         traverse_leaves(sc, ray, R(0.001), rng, t, best, cnt);
       } else if constexpr (!ORDERED) {
-        traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+        if constexpr (INST == 0)  // (as render_kernel: compiled for scenes without / with instances)
+          traverse_impl<false>(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+        else if constexpr (INST == 1)
+          traverse_impl<true>(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
+        else
+          traverse(sc, ray, R(0.001), rng, stack, (uint32_t)BLOCK, t, best, cnt);
       }
       RT_STAMP(4);  // walk
       Vec3<R> L(0, 0, 0);  // set once, at the path's last vertex (see render_persist_kernel)

@@ -192,6 +192,15 @@ hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const SceneView<RT_REAL>& sc, const
     return hipGetLastError();
   }
   if constexpr (!F64) {
+    if (shape.unit_samples > 0 && shape.trav == TRAV_REFERENCE && !sc.has_instances) {  // queue form (rt_api.hip: make_shape)
+      if (stats)
+        RT_LAUNCH((render_queue_kernel<RT_REAL, true, TRAV_REFERENCE, RT_EARLY_EXIT, false, 0>), grid, block, lds, st, sc, cam, a,
+                  accum, dstats);
+      else
+        RT_LAUNCH((render_queue_kernel<RT_REAL, false, TRAV_REFERENCE, RT_EARLY_EXIT, false, 0>), grid, block, lds, st, sc, cam, a,
+                  accum, dstats);
+      return hipGetLastError();
+    }
     if (sc.has_instances) {
       if (stats)
         RT_LAUNCH((render_kernel<RT_REAL, true, RT_EARLY_EXIT, TRAV_REFERENCE, false, 1>), grid, block, lds, st, sc, cam, a,

@@ -1143,7 +1143,16 @@ LaunchShape make_shape(const rt_scene* s, uint32_t w, uint32_t h, uint32_t n_sam
   // workgroup per (tile, split) (A/B).  Not for the f32 reference-order kernel: its jobs are short-path scenes
   // (the reference's default job, depth 5: 35.9 ms as a grid, 38.2 ms at best in this form).
   static const bool ref_grid = getenv("RT_REF_GRID") != nullptr;
-  if ((sh.trav == 0 || sh.trav == 3 || ordered64) && f64 && (!ref_grid || sh.trav != 0) && max_depth > 0 && n_samples > 0) {
+  // The f32 reference-order kernel (scenes whose boxes clip — the reference's default scene —, RT_FLAG_FORCE_BVH) takes the
+  // queue form too (render_queue_kernel<float, ..., TRAV_REFERENCE>) from 16 samples per launch on: the reference's default
+  // job (simple_light 1200 x 800 x 500 spp, depth 5) 35.5 -> 34.1 ms, simple_light 400 x 267 x 100 spp 1.3 -> 1.0 ms, forced
+  // walks of Cornell 1024^2 x 256 spp 26.8 -> 23.2 ms, random_scene C1 13.7 -> 10.7 ms, final_scene 512^2 x 16 spp 12.2 -> 11.0 ms;
+  // at 4 spp (Cornell 3840 x 2160) the grid form wins, 3.0 vs 3.5 ms.  Not the instantiations that carry the extension
+  // code or the instance arm (they stay one workgroup per tile).  RT_QUEUE_REF32=0: the grid form (A/B).
+  static const bool queue_ref32 = getenv("RT_QUEUE_REF32") == nullptr || atoi(getenv("RT_QUEUE_REF32")) != 0;
+  const bool ref32_units = queue_ref32 && !f64 && sh.trav == 0 && n_samples >= 16 && !s->f32.view.has_noise &&
+                           !s->f32.view.has_instances;
+  if ((((sh.trav == 0 || sh.trav == 3 || ordered64) && f64 && (!ref_grid || sh.trav != 0)) || ref32_units) && max_depth > 0 && n_samples > 0) {
     // (leaf-list form at the metric's 4096 spp, units of 16 / 32 / 64 / 128 / 256 samples: 1511 / 1518 / 1545 / 1603 / 1751 ms)
     const uint32_t auto_unit = sh.trav == 3 ? std::min(16u, std::max(2u, n_samples / 32)) : std::min(8u, std::max(2u, n_samples / 16));
     sh.unit_samples = std::max(1u, std::min(us ? (uint32_t)std::max(1, atoi(us)) : auto_unit, n_samples));
